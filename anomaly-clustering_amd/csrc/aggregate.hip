@@ -1,0 +1,240 @@
+// Patch aggregation on gfx950: tapped feature maps -> per-patch embedding matrix Z.
+//
+// Reference arithmetic (paths relative to Anomaly-Clustering/):
+//   models/patchcore/patchcore.py:375-385  CLS drop, [B,T,C] -> [B,C,H,W], fresh LayerNorm([C,H,W]) (eps 1e-5)
+//   models/patchcore/patchcore.py:439-465  Unfold(k, stride 1, pad (k-1)/2): patch vector index e = c*k*k + ky*k + kx
+//   models/patchcore/patchcore.py:398-421  bilinear (align_corners=False) resize of the patch GRID to layer 0's grid
+//   models/patchcore/common.py:163-170     adaptive_avg_pool1d(C*k*k -> pre_dim) per layer
+//   models/patchcore/common.py:173-183     adaptive_avg_pool1d(n_layers*pre_dim -> tgt_dim)
+//
+// The reference materialises the unfolded tensor (9x the feature map) in HBM and copies it
+// several times; here one workgroup owns one output row of Z, builds that patch's unfolded,
+// standardised, grid-aligned vector in LDS (e-order, so every pooling window is a contiguous
+// LDS range) and writes the 16 KB row of Z once.  HBM-bound on the Z write; the feature maps
+// are re-read from L2 (each token is needed by k*k neighbouring patches).
+#include "common.h"
+
+// ---- pass 1: per (layer, image) sum and sum of squares over C*H*W values, fp64
+__global__ __launch_bounds__(256) void agg_stats_kernel(const float* __restrict__ f, int kind, int C, int HW,
+                                                        double* __restrict__ stats /* [B][2] */) {
+  const int b = blockIdx.y;
+  // both kinds: the image's values are one contiguous range (tokens: after the CLS row)
+  const size_t n = (size_t)C * HW;
+  const float* base = f + (kind == AC_FEAT_TOKENS ? ((size_t)b * (HW + 1) + 1) * C : (size_t)b * n);
+  double s = 0.0, ss = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double v = base[i];
+    s += v;
+    ss += v * v;
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  __shared__ double red[2][4];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = s; red[1][wv] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[b * 2 + 0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&stats[b * 2 + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+struct AggLayer {
+  const float* f;
+  const double* stats;   // [B][2]
+  int kind, C, H, W;
+};
+struct AggParams {
+  AggLayer layer[4];
+  int n_layers, k, pre, tgt, H0, W0;
+  float eps;
+  float* Z;
+};
+
+// torch's area_pixel_compute_source_index for bilinear, align_corners=False
+__device__ inline void bilinear_src(int dst, int in_size, int out_size, int& i0, int& i1, float& l0, float& l1) {
+  if (in_size == out_size) { i0 = i1 = dst; l0 = 1.f; l1 = 0.f; return; }
+  float scale = (float)in_size / (float)out_size;
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// ---- pass 2: one workgroup per (reference-grid patch, image)
+__global__ __launch_bounds__(256) void agg_pool_kernel(AggParams prm) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int patch = blockIdx.x, b = blockIdx.y;
+  const int y = patch / prm.W0, x = patch - y * prm.W0;
+  const int k = prm.k, k2 = k * k, pad = (k - 1) / 2;
+  int maxL = 0;
+  for (int l = 0; l < prm.n_layers; ++l) maxL = max(maxL, prm.layer[l].C * k2);
+  float* U = lds;                 // [maxL] unfolded, standardised, aligned patch vector of the current layer
+  float* V = lds + maxL;          // [n_layers*pre] pooled layers (only when the final pool is not the identity)
+  const bool identity = (prm.n_layers * prm.pre == prm.tgt);
+  float* zrow = prm.Z + ((size_t)b * prm.H0 * prm.W0 + patch) * prm.tgt;
+
+  for (int l = 0; l < prm.n_layers; ++l) {
+    const AggLayer L = prm.layer[l];
+    const int HW = L.H * L.W, Lk = L.C * k2;
+    const double n = (double)L.C * HW;
+    const double mean_d = L.stats[b * 2] / n;
+    const double var_d = fmax(L.stats[b * 2 + 1] / n - mean_d * mean_d, 0.0);
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)prm.eps));
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bilinear_src(y, L.H, prm.H0, y0, y1, ly0, ly1);
+    bilinear_src(x, L.W, prm.W0, x0, x1, lx0, lx1);
+    const bool same_grid = (L.H == prm.H0 && L.W == prm.W0);
+
+    // standardised value of channel c at own-grid position (yy, xx); 0 outside (Unfold's zero padding
+    // is applied AFTER the LayerNorm)
+    auto val = [&](int c, int yy, int xx) -> float {
+      if (yy < 0 || yy >= L.H || xx < 0 || xx >= L.W) return 0.f;
+      size_t idx = (L.kind == AC_FEAT_TOKENS) ? ((size_t)b * (HW + 1) + 1 + yy * L.W + xx) * L.C + c
+                                              : (((size_t)b * L.C + c) * L.H + yy) * L.W + xx;
+      return (L.f[idx] - mean) * rstd;
+    };
+    if (L.kind == AC_FEAT_TOKENS) {
+      // channel on the thread: global reads contiguous in c; LDS writes at stride k2 floats
+      for (int kk = 0; kk < k2; ++kk) {
+        const int dy = kk / k - pad, dx = kk - (kk / k) * k - pad;
+        for (int c = tid; c < L.C; c += 256) {
+          float v;
+          if (same_grid) v = val(c, y + dy, x + dx);
+          else
+            v = ly0 * (lx0 * val(c, y0 + dy, x0 + dx) + lx1 * val(c, y0 + dy, x1 + dx)) +
+                ly1 * (lx0 * val(c, y1 + dy, x0 + dx) + lx1 * val(c, y1 + dy, x1 + dx));
+          U[c * k2 + kk] = v;
+        }
+      }
+    } else {
+      for (int e = tid; e < Lk; e += 256) {
+        const int c = e / k2, kk = e - c * k2;
+        const int dy = kk / k - pad, dx = kk - (kk / k) * k - pad;
+        float v;
+        if (same_grid) v = val(c, y + dy, x + dx);
+        else
+          v = ly0 * (lx0 * val(c, y0 + dy, x0 + dx) + lx1 * val(c, y0 + dy, x1 + dx)) +
+              ly1 * (lx0 * val(c, y1 + dy, x0 + dx) + lx1 * val(c, y1 + dy, x1 + dx));
+        U[e] = v;
+      }
+    }
+    __syncthreads();
+    // adaptive_avg_pool1d(Lk -> pre): window [floor(o*Lk/pre), ceil((o+1)*Lk/pre)), sequential fp32 sum / length
+    for (int o = tid; o < prm.pre; o += 256) {
+      const int s = (int)(((long long)o * Lk) / prm.pre);
+      const int e = (int)((((long long)(o + 1)) * Lk + prm.pre - 1) / prm.pre);
+      float acc = 0.f;
+      for (int i = s; i < e; ++i) acc += U[i];
+      const float r = acc / (float)(e - s);
+      if (identity) zrow[l * prm.pre + o] = r;
+      else V[l * prm.pre + o] = r;
+    }
+    __syncthreads();
+  }
+  if (!identity) {
+    const int Lv = prm.n_layers * prm.pre;
+    for (int t = tid; t < prm.tgt; t += 256) {
+      const int s = (int)(((long long)t * Lv) / prm.tgt);
+      const int e = (int)((((long long)(t + 1)) * Lv + prm.tgt - 1) / prm.tgt);
+      float acc = 0.f;
+      for (int i = s; i < e; ++i) acc += V[i];
+      zrow[t] = acc / (float)(e - s);
+    }
+  }
+}
+
+extern "C" size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C, const int* H, const int* W, int B,
+                                                     int patchsize, int pre_dim, int tgt_dim) {
+  (void)C; (void)H; (void)W; (void)patchsize; (void)pre_dim; (void)tgt_dim;
+  if (n_layers <= 0 || B <= 0) return 256;
+  return align_up((size_t)n_layers * B * 2 * sizeof(double), 256) + 256;
+}
+
+extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, const int* C, const int* H, const int* W,
+                                  int n_layers, int B, int patchsize, int pre_dim, int tgt_dim, float eps, float* Z,
+                                  void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(feats && kind && C && H && W && Z && ws, "ac_patch_aggregate: null pointer");
+  AC_REQUIRE(n_layers >= 1 && n_layers <= 4, "ac_patch_aggregate: n_layers=%d must be 1..4", n_layers);
+  AC_REQUIRE(patchsize >= 1 && (patchsize & 1), "ac_patch_aggregate: patchsize=%d must be odd (stride-1 unfold keeps the grid)",
+             patchsize);
+  AC_REQUIRE(pre_dim > 0 && tgt_dim > 0, "ac_patch_aggregate: bad dims");
+  AC_REQUIRE(B > 0 && B <= 65535, "ac_patch_aggregate: B=%d out of range", B);
+  if (ws_bytes < ac_patch_aggregate_workspace_bytes(n_layers, C, H, W, B, patchsize, pre_dim, tgt_dim))
+    return ac_fail(AC_EWORKSPACE, "ac_patch_aggregate: workspace too small");
+  AggParams prm;
+  prm.n_layers = n_layers; prm.k = patchsize; prm.pre = pre_dim; prm.tgt = tgt_dim;
+  prm.H0 = H[0]; prm.W0 = W[0]; prm.eps = eps; prm.Z = Z;
+  double* stats = static_cast<double*>(ws);
+  (void)hipMemsetAsync(stats, 0, (size_t)n_layers * B * 2 * sizeof(double), stream);
+  int maxL = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    AC_REQUIRE(feats[l] && C[l] > 0 && H[l] > 0 && W[l] > 0, "ac_patch_aggregate: bad layer %d", l);
+    AC_REQUIRE(kind[l] == AC_FEAT_TOKENS || kind[l] == AC_FEAT_NCHW, "ac_patch_aggregate: bad kind for layer %d", l);
+    prm.layer[l] = AggLayer{feats[l], stats + (size_t)l * B * 2, kind[l], C[l], H[l], W[l]};
+    maxL = maxL > C[l] * patchsize * patchsize ? maxL : C[l] * patchsize * patchsize;
+    size_t n = (size_t)C[l] * H[l] * W[l];
+    int chunks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(agg_stats_kernel, dim3(chunks, B), dim3(256), 0, stream, feats[l], kind[l], C[l], H[l] * W[l],
+                       stats + (size_t)l * B * 2);
+  }
+  size_t lds = ((size_t)maxL + (size_t)n_layers * pre_dim) * sizeof(float);
+  AC_REQUIRE(lds <= 160 * 1024, "ac_patch_aggregate: C*k*k + layers*pre_dim = %zu floats exceeds LDS", lds / 4);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL(agg_pool_kernel, dim3(H[0] * W[0], B), dim3(256), lds, stream, prm);
+  return ac_check_launch("ac_patch_aggregate");
+}
+
+// ------------------------------------------------ stand-alone unfold / pool
+__global__ void unfold_kernel(const float* __restrict__ x, int B, int C, int H, int W, int k, float* __restrict__ out) {
+  const int k2 = k * k, pad = (k - 1) / 2;
+  size_t total = (size_t)B * H * W * C * k2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int kk = (int)(i % k2);
+    size_t t = i / k2;
+    int c = (int)(t % C); t /= C;
+    int p = (int)(t % (H * W));
+    int b = (int)(t / (H * W));
+    int yy = p / W + kk / k - pad, xx = p % W + kk % k - pad;
+    out[i] = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.f : x[(((size_t)b * C + c) * H + yy) * W + xx];
+  }
+}
+
+extern "C" int ac_unfold_patches(const float* x, int B, int C, int H, int W, int patchsize, float* out, void* stream) {
+  AC_REQUIRE(x && out, "ac_unfold_patches: null pointer");
+  AC_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && patchsize >= 1 && (patchsize & 1), "ac_unfold_patches: bad shape");
+  size_t total = (size_t)B * H * W * C * patchsize * patchsize;
+  unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(unfold_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, B, C, H, W, patchsize, out);
+  return ac_check_launch("ac_unfold_patches");
+}
+
+__global__ void pool_rows_kernel(const float* __restrict__ x, int64_t rows, int L, int O, float* __restrict__ y) {
+  const int64_t row = blockIdx.y;
+  const float* xr = x + row * L;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < O; o += gridDim.x * 256) {
+    const int s = (int)(((long long)o * L) / O);
+    const int e = (int)((((long long)(o + 1)) * L + O - 1) / O);
+    float acc = 0.f;
+    for (int i = s; i < e; ++i) acc += xr[i];
+    y[row * O + o] = acc / (float)(e - s);
+  }
+}
+
+extern "C" int ac_adaptive_avg_pool_rows(const float* x, int64_t rows, int L, int O, float* y, void* stream) {
+  AC_REQUIRE(x && y, "ac_adaptive_avg_pool_rows: null pointer");
+  AC_REQUIRE(L > 0 && O > 0 && rows >= 0 && rows <= 65535LL * 65535LL, "ac_adaptive_avg_pool_rows: bad shape");
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    int64_t n = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(pool_rows_kernel, dim3((O + 255) / 256, (unsigned)n), dim3(256), 0, as_stream(stream),
+                       x + r0 * L, n, L, O, y + r0 * O);
+  }
+  return ac_check_launch("ac_adaptive_avg_pool_rows");
+}

@@ -1,0 +1,337 @@
+// alpha-weight path on gfx950: all-pairs patch distance with fused min-reduce (MFMA),
+// fp64 softmax, weighted-average embedding, condensed pdist.
+// Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
+// scipy pdist under examples/test.py:193-195.
+#include "gemm_hl.h"
+
+// ------------------------------------------------------------------ packing
+// fp32 [rows, K] -> hl32 + optional squared row norms.  One wave per row; each lane
+// converts 8 consecutive floats per trip (two 16-byte loads in, hi/lo 16-byte stores out).
+__global__ __launch_bounds__(256) void pack_hl32_kernel(const float* __restrict__ src, int64_t rows, int K,
+                                                        int64_t ld, uint8_t* __restrict__ dst,
+                                                        float* __restrict__ sqnorm) {
+  int lane = threadIdx.x & 63;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = src + row * ld;
+  uint8_t* d = dst + (size_t)row * K * 4;
+  double acc = 0.0;   // fp64 sum of squares, rounded once: the norm enters d2 at ~5x its magnitude
+  for (int k = lane * 8; k < K; k += 512) {
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(s + k);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(s + k + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (double)v[j] * (double)v[j];
+    store_hl32_8(d, k, v);
+  }
+  if (sqnorm) {
+    acc = wave_sum(acc);
+    if (lane == 0) sqnorm[row] = (float)acc;
+  }
+}
+
+extern "C" int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_ld, void* dst, float* row_sqnorm,
+                            void* stream) {
+  AC_REQUIRE(src && dst, "ac_pack_hl32: null pointer");
+  AC_REQUIRE(K > 0 && K % 32 == 0, "ac_pack_hl32: K=%d must be a positive multiple of 32", K);
+  AC_REQUIRE(src_ld >= K && src_ld % 4 == 0, "ac_pack_hl32: src_ld=%lld must be >= K and a multiple of 4",
+             (long long)src_ld);
+  AC_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "ac_pack_hl32: pointers must be 16-byte aligned");
+  if (rows <= 0) return AC_OK;
+  int64_t blocks = (rows + 3) / 4;
+  AC_REQUIRE(blocks <= 0x7fffffff, "ac_pack_hl32: too many rows");
+  hipLaunchKernelGGL(pack_hl32_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, rows, K,
+                     src_ld, static_cast<uint8_t*>(dst), row_sqnorm);
+  return ac_check_launch("pack_hl32");
+}
+
+// ------------------------------------------------- pair-min-distance epilogue
+// GEMM orientation: A (rows -> accumulator registers) = KEY patches, flat over all key
+// images; B (columns -> lanes) = QUERY patches.  d2(key, q) = |key|^2 + |q|^2 - 2 key.q,
+// clamped at 0 (torch.cdist's clamp_min, utils.py:226 via torch).  The min over the key
+// patches of ONE key image is an in-lane min over registers, one lane-half exchange, and one
+// atomicMin per (key image, query column) into minbuf[key_image][query] (d2 >= 0, so the
+// IEEE bit pattern orders like an unsigned integer).
+struct EpiPairMin {
+  const float* key_sq;   // [M]
+  const float* qry_sq;   // [N]
+  unsigned* minbuf;      // [n_key_images][N]
+  int M, N, P;
+  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
+    const int r = lane & 31, h = lane >> 5;
+    if (m_wave >= M) return;                      // wave-uniform
+    const int m_end = min(m_wave + 64, M);
+    float ksq[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        ksq[mi][i] = key_sq[min(row, M - 1)];
+      }
+    const int img_first = m_wave / P, img_last = (m_end - 1) / P;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n_wave + ni * 32 + r;
+      const float qs = qry_sq[min(col, N - 1)];
+      float d2[2][16];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)   // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
+          d2[mi][i] = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+      for (int img = img_first; img <= img_last; ++img) {   // wave-uniform trip count (<= 2 when P >= 64)
+        const int lo = img * P, hi = min(lo + P, m_end);
+        float mn = __builtin_inff();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            mn = (row >= lo && row < hi) ? fminf(mn, d2[mi][i]) : mn;
+          }
+        mn = fminf(mn, __shfl_xor(mn, 32, 64));
+        if (h == 0 && col < N) atomicMin(minbuf + (size_t)img * N + col, __float_as_uint(mn));
+      }
+    }
+  }
+};
+
+__global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// w[q_img][p] from minbuf[key_img][q]: sqrt, then mean over key images != self, or min over all.
+__global__ void reduce_pairs_kernel(const unsigned* __restrict__ minbuf, int64_t nk, int64_t ncols, int P,
+                                    int reduce, int64_t self_first, float* __restrict__ w) {
+  int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  int64_t self = self_first + col / P;
+  if (reduce == AC_REDUCE_MEAN_OTHERS) {
+    double s = 0.0;
+    for (int64_t j = 0; j < nk; ++j)
+      if (j != self) s += (double)sqrtf(__uint_as_float(minbuf[j * ncols + col]));
+    int64_t cnt = nk - ((self >= 0 && self < nk) ? 1 : 0);
+    w[col] = (float)(s / (double)cnt);          // cnt == 0 -> NaN, as torch.mean of an empty tensor
+  } else {
+    float m = __builtin_inff();
+    for (int64_t j = 0; j < nk; ++j) m = fminf(m, __uint_as_float(minbuf[j * ncols + col]));
+    w[col] = sqrtf(m);
+  }
+}
+
+static const size_t kMinbufBudget = (size_t)1 << 30;   // bytes of minbuf per query chunk
+
+static int64_t query_chunk(int64_t nq, int64_t nk, int P) {
+  size_t per_img = (size_t)nk * P * 4;
+  int64_t c = (int64_t)(kMinbufBudget / (per_img ? per_img : 1));
+  if (c < 1) c = 1;
+  return c < nq ? c : nq;
+}
+
+extern "C" size_t ac_pair_min_dist_workspace_bytes(int64_t nq, int64_t nk, int P, int D) {
+  if (nq <= 0 || nk <= 0 || P <= 0 || D <= 0) return 256;
+  size_t hl_k = align_up((size_t)nk * P * D * 4, 256), hl_q = align_up((size_t)nq * P * D * 4, 256);
+  size_t n_k = align_up((size_t)nk * P * 4, 256), n_q = align_up((size_t)nq * P * 4, 256);
+  size_t mb = align_up((size_t)query_chunk(nq, nk, P) * P * nk * 4, 256);
+  return hl_k + hl_q + n_k + n_q + mb + 1024;
+}
+
+extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, int P, int D, int reduce,
+                                int64_t self_offset, float* w, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(Zq && Zk && w && ws, "ac_pair_min_dist: null pointer");
+  AC_REQUIRE(nq > 0 && nk > 0 && P > 0, "ac_pair_min_dist: empty input (nq=%lld nk=%lld P=%d)", (long long)nq,
+             (long long)nk, P);
+  AC_REQUIRE(D > 0 && D % 32 == 0, "ac_pair_min_dist: D=%d must be a positive multiple of 32", D);
+  AC_REQUIRE(reduce == AC_REDUCE_MEAN_OTHERS || reduce == AC_REDUCE_MIN_ALL, "ac_pair_min_dist: bad reduce=%d", reduce);
+  AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_dist: too many patches for int32 tiles");
+  if (ws_bytes < ac_pair_min_dist_workspace_bytes(nq, nk, P, D))
+    return ac_fail(AC_EWORKSPACE, "ac_pair_min_dist: workspace %zu < %zu", ws_bytes,
+                   ac_pair_min_dist_workspace_bytes(nq, nk, P, D));
+  Arena ar(ws, ws_bytes);
+  const bool same = (Zq == Zk && nq == nk);
+  uint8_t* hk = ar.take<uint8_t>((size_t)nk * P * D * 4);
+  float* sk = ar.take<float>((size_t)nk * P);
+  uint8_t* hq = same ? hk : ar.take<uint8_t>((size_t)nq * P * D * 4);
+  float* sq = same ? sk : ar.take<float>((size_t)nq * P);
+  const int64_t chunk = query_chunk(nq, nk, P);
+  unsigned* minbuf = ar.take<unsigned>((size_t)chunk * P * nk);
+  if (!ar.ok()) return ac_fail(AC_EWORKSPACE, "ac_pair_min_dist: workspace carve failed");
+
+  int rc = ac_pack_hl32(Zk, nk * P, D, D, hk, sk, stream_);
+  if (rc) return rc;
+  if (!same) {
+    rc = ac_pack_hl32(Zq, nq * P, D, D, hq, sq, stream_);
+    if (rc) return rc;
+  }
+  const int M = (int)(nk * P);
+  for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+    const int64_t qn = (q0 + chunk <= nq) ? chunk : nq - q0;
+    const int N = (int)(qn * P);
+    size_t cells = (size_t)nk * N;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096)),
+                       dim3(256), 0, stream, minbuf, cells, 0x7f800000u);
+    EpiPairMin epi{sk, sq + q0 * P, minbuf, M, N, P};
+    rc = gemm::launch(hk, hq + (size_t)q0 * P * D * 4, M, N, D, epi, stream, 16);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, minbuf, nk,
+                       (int64_t)N, P, reduce, self_offset + q0, w + q0 * P);
+  }
+  return ac_check_launch("ac_pair_min_dist");
+}
+
+// ------------------------------------------------------------ alpha softmax
+// One block per image.  fp64 throughout (utils.py:245, 253-254): alpha = k*exp(w/tau)/sum.
+// The max is subtracted before exp - mathematically identical, and finite where the
+// reference's un-shifted exp overflows.  tau == 0 (math.isclose(tau, 0) with its default
+// abs_tol = 0 is true only for exact zero): indicator of the maximum over #ties.
+__global__ __launch_bounds__(256) void alpha_softmax_kernel(const float* __restrict__ w, int P, double tau, double k,
+                                                            double* __restrict__ alpha) {
+  __shared__ double red[4];
+  __shared__ double bcast;
+  const float* wi = w + (size_t)blockIdx.x * P;
+  double* ai = alpha + (size_t)blockIdx.x * P;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float m = -__builtin_inff();
+  for (int p = tid; p < P; p += 256) m = fmaxf(m, wi[p]);
+  m = wave_max(m);
+  if (lane == 0) red[wv] = (double)m;
+  __syncthreads();
+  if (tid == 0) bcast = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  const double mx = bcast;
+  __syncthreads();
+  double s = 0.0;
+  const bool hard = (tau == 0.0);
+  const double inv_tau = hard ? 0.0 : 1.0 / tau;
+  for (int p = tid; p < P; p += 256) {
+    double v = hard ? ((double)wi[p] == mx ? 1.0 : 0.0) : k * exp(inv_tau * ((double)wi[p] - mx));
+    ai[p] = v;
+    s += v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  if (tid == 0) bcast = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  const double tot = bcast;
+  for (int p = tid; p < P; p += 256) ai[p] = ai[p] / tot;
+}
+
+extern "C" int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, void* stream) {
+  AC_REQUIRE(w && alpha, "ac_alpha_softmax: null pointer");
+  AC_REQUIRE(P > 0 && N >= 0 && N <= 0x7fffffff, "ac_alpha_softmax: bad shape N=%lld P=%d", (long long)N, P);
+  AC_REQUIRE(tau >= 0.0, "ac_alpha_softmax: tau=%g must be >= 0", tau);
+  if (N == 0) return AC_OK;
+  hipLaunchKernelGGL(alpha_softmax_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), w, P, tau, k, alpha);
+  return ac_check_launch("alpha_softmax");
+}
+
+// --------------------------------------------------------- weighted average
+// X[i][d] = sum_p alpha[i][p] * Z[i][p][d].  HBM-bound (reads Z once): block = (image, 1024
+// columns, one of S patch slices), each thread owns 4 consecutive columns (16-byte loads,
+// a wave reads 1 KB contiguous per patch row); slices combine through fp32 atomics only when
+// S > 1 (small N), otherwise plain stores.
+__global__ __launch_bounds__(256) void weighted_avg_kernel(const float* __restrict__ alpha, const float* __restrict__ Z,
+                                                           int P, int D, int slices, float* __restrict__ X) {
+  const int img = blockIdx.z, slice = blockIdx.y;
+  const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (d >= D) return;
+  const int per = (P + slices - 1) / slices;
+  const int p0 = slice * per, p1 = min(P, p0 + per);
+  const float* a = alpha + (size_t)img * P;
+  const float* z = Z + ((size_t)img * P) * D + d;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  int p = p0;
+  for (; p + 1 < p1; p += 2) {
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(z + (size_t)p * D);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(z + (size_t)(p + 1) * D);
+    float a0 = a[p], a1 = a[p + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc0[j] = fmaf(a0, v0[j], acc0[j]); acc1[j] = fmaf(a1, v1[j], acc1[j]); }
+  }
+  if (p < p1) {
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(z + (size_t)p * D);
+    float a0 = a[p];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[j] = fmaf(a0, v0[j], acc0[j]);
+  }
+  float* x = X + (size_t)img * D + d;
+  if (slices == 1) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = acc0[j] + acc1[j];
+    *reinterpret_cast<f32x4*>(x) = o;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(x + j, acc0[j] + acc1[j]);
+  }
+}
+
+extern "C" int ac_weighted_avg(const float* alpha, const float* Z, int64_t N, int P, int D, float* X, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(alpha && Z && X, "ac_weighted_avg: null pointer");
+  AC_REQUIRE(P > 0 && D > 0 && D % 4 == 0, "ac_weighted_avg: bad shape P=%d D=%d (D %% 4 == 0)", P, D);
+  AC_REQUIRE(N >= 0 && N <= 65535, "ac_weighted_avg: N=%lld out of range (<= 65535 per call)", (long long)N);
+  if (N == 0) return AC_OK;
+  int col_blocks = (D / 4 + 255) / 256;
+  // enough blocks to cover the chip (256 CUs x ~8) without atomics when N is already large
+  int slices = 1;
+  while ((int64_t)N * col_blocks * slices < 2048 && slices * 2 <= 16 && P / (slices * 2) >= 16) slices *= 2;
+  if (slices > 1) (void)hipMemsetAsync(X, 0, (size_t)N * D * 4, stream);
+  hipLaunchKernelGGL(weighted_avg_kernel, dim3(col_blocks, slices, (unsigned)N), dim3(256), 0, stream, alpha, Z, P, D,
+                     slices, X);
+  return ac_check_launch("weighted_avg");
+}
+
+// -------------------------------------------------------------------- pdist
+// Condensed Euclidean distances in float64 (scipy pdist on the float64 copy of X,
+// examples/test.py:186-195): d(i,j) = sqrt(sum_k (x_ik - x_jk)^2), differences and
+// accumulation in fp64.  32x32 pairs per block, rows staged through LDS in 64-wide K slices.
+__global__ __launch_bounds__(256) void pdist_kernel(const float* __restrict__ X, int64_t N, int D,
+                                                    double* __restrict__ out) {
+  __shared__ float sa[32][65], sb[32][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;                                   // upper triangle of 32x32 tiles
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;                // each thread: rows {ti, ti+16} x cols {tj, tj+16}
+  double acc[2][2] = {{0, 0}, {0, 0}};
+  for (int k0 = 0; k0 < D; k0 += 64) {
+    for (int e = tid; e < 32 * 64; e += 256) {
+      int rr = e >> 6, kk = e & 63;
+      int64_t ra = (int64_t)bi * 32 + rr, rb = (int64_t)bj * 32 + rr;
+      sa[rr][kk] = (ra < N && k0 + kk < D) ? X[ra * D + k0 + kk] : 0.f;
+      sb[rr][kk] = (rb < N && k0 + kk < D) ? X[rb * D + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) {
+      double a0 = sa[ti][kk], a1 = sa[ti + 16][kk], b0 = sb[tj][kk], b1 = sb[tj + 16][kk];
+      double d;
+      d = a0 - b0; acc[0][0] = fma(d, d, acc[0][0]);
+      d = a0 - b1; acc[0][1] = fma(d, d, acc[0][1]);
+      d = a1 - b0; acc[1][0] = fma(d, d, acc[1][0]);
+      d = a1 - b1; acc[1][1] = fma(d, d, acc[1][1]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      int64_t i = (int64_t)bi * 32 + ti + 16 * u, j = (int64_t)bj * 32 + tj + 16 * v;
+      if (i < j && j < N) out[i * N - i * (i + 1) / 2 + (j - i - 1)] = sqrt(acc[u][v]);
+    }
+}
+
+extern "C" int ac_pdist(const float* X, int64_t N, int D, double* out, void* stream) {
+  AC_REQUIRE(X && (out || N < 2), "ac_pdist: null pointer");
+  AC_REQUIRE(D > 0 && N >= 0 && N <= 32 * 65535LL, "ac_pdist: bad shape N=%lld D=%d", (long long)N, D);
+  if (N < 2) return AC_OK;
+  unsigned t = (unsigned)((N + 31) / 32);
+  hipLaunchKernelGGL(pdist_kernel, dim3(t, t), dim3(256), 0, as_stream(stream), X, N, D, out);
+  return ac_check_launch("pdist");
+}

@@ -1,0 +1,74 @@
+// Shared host/device helpers for the gfx950 anomaly-clustering kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ac_hip.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error reporting (thread-local message, C ABI returns a code)
+int ac_fail(int code, const char* fmt, ...);
+int ac_check_launch(const char* what);
+
+#define AC_REQUIRE(cond, ...) do { if (!(cond)) return ac_fail(AC_EINVAL, __VA_ARGS__); } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace (256-byte aligned slices).
+struct Arena {
+  uint8_t* base; size_t size; size_t off;
+  Arena(void* p, size_t n) : base(static_cast<uint8_t*>(p)), size(n), off(0) {}
+  template <class T> T* take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T), 256);
+    if (off + bytes > size) { off = size + 1; return nullptr; }
+    T* r = reinterpret_cast<T*>(base + off); off += bytes; return r;
+  }
+  bool ok() const { return off <= size; }
+};
+
+// ---- hl32 addressing: element (row, k) of a [rows, K] matrix
+//   hi at row*K*4 + (k/32)*128 + (k%32)*2 ; lo at +64.
+__host__ __device__ inline size_t hl32_row_bytes(int K) { return (size_t)K * 4; }
+
+// Split 8 consecutive floats (k % 8 == 0) into the hi / lo fp16 vectors of hl32.
+__device__ inline void split8(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)(v[j] - (float)h);
+  }
+}
+
+// Store 8 consecutive columns [k, k+8) of one hl32 row.
+__device__ inline void store_hl32_8(uint8_t* row_base, int k, const float* v) {
+  half8 hi, lo;
+  split8(v, hi, lo);
+  uint8_t* p = row_base + (size_t)(k >> 5) * 128 + (size_t)(k & 31) * 2;
+  *reinterpret_cast<half8*>(p) = hi;
+  *reinterpret_cast<half8*>(p + 64) = lo;
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

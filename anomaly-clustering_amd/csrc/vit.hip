@@ -1,0 +1,483 @@
+// DINO ViT forward on gfx950: patch embedding, LayerNorm, fused-QKV attention and MLP.
+// Reference arithmetic: models/patchcore/vision_transformer.py (PatchEmbed :128-131,
+// prepare_tokens :196-207, Attention :80-92, Mlp :59-65, Block :107-113; eps 1e-6 from :253).
+//
+// Every dense contraction (patch projection, qkv, QK^T, PV, proj, fc1, fc2) runs on
+// v_mfma_f32_32x32x16_f16 in the 3-pass split-fp16 scheme (gemm_hl.h), so the result is
+// fp32-grade like the reference's fp32 CPU path.  The residual stream x stays fp32 in HBM;
+// everything that feeds an MFMA (LN output, q/k/v, attention output, GELU output) is written
+// directly in hl32 form by the producing kernel's epilogue - same bytes as fp32, no
+// conversion pass.
+#include "gemm_hl.h"
+
+constexpr int HD = 64;          // head dim (all DINO ViTs)
+
+__host__ __device__ inline int tpad_of(int T) { return (T + 31) / 32 * 32; }
+
+// ------------------------------------------------------------------ im2col
+// images [B, Cin, S, S] -> hl32 [B*G*G, Cin*p*p], k = c*p*p + ky*p + kx (conv weight flattening).
+// One thread per 8 consecutive k (8 | p, so the 8 pixels are contiguous in the image row).
+__global__ __launch_bounds__(256) void im2col_hl_kernel(const float* __restrict__ img, int B, int Cin, int S, int p,
+                                                        uint8_t* __restrict__ out) {
+  const int G = S / p, Kd = Cin * p * p, cpr = Kd / 8;
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)B * G * G * cpr;
+  if (idx >= total) return;
+  int ch = (int)(idx % cpr);
+  size_t row = idx / cpr;
+  int k = ch * 8;
+  int c = k / (p * p), rem = k - c * p * p, ky = rem / p, kx = rem - ky * p;
+  int b = (int)(row / (G * G)), pp = (int)(row - (size_t)b * G * G), py = pp / G, px = pp - py * G;
+  const float* src = img + (((size_t)b * Cin + c) * S + (py * p + ky)) * S + px * p + kx;
+  float v[8];
+  *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+  *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+  store_hl32_8(out + row * Kd * 4, k, v);
+}
+
+__global__ void set_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos, int B, int T, int C,
+                               float* __restrict__ x) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  int b = i / C, c = i - b * C;
+  x[(size_t)b * T * C + c] = cls[c] + pos[c];
+}
+
+// rows = patches (b*G*G + p), cols = embedding channel: x[b][1+p][col] = acc + bias + pos[1+p]
+struct EpiPatchEmbed {
+  const float* bias; const float* pos; float* x; int M, N, PP, T;
+  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n_wave + ni * 32 + r;
+      if (col >= N) continue;
+      const float bc = bias[col];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < M) {
+            int b = row / PP, p = row - b * PP;
+            x[((size_t)b * T + 1 + p) * N + col] = (f.acc[mi][ni][i] + bc) + pos[(size_t)(1 + p) * N + col];
+          }
+        }
+    }
+  }
+};
+
+// --------------------------------------------------------------- LayerNorm
+// One wave per row; the row lives in registers (C <= 2048), two-pass mean / variance in fp32.
+template <bool HL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, uint8_t* __restrict__ out_hl, float* __restrict__ out_f) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  const int nch = C / 8;
+  float v[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int ch = lane + 64 * t;
+    if (ch < nch) {
+      *reinterpret_cast<f32x4*>(v[t]) = *reinterpret_cast<const f32x4*>(xr + ch * 8);
+      *reinterpret_cast<f32x4*>(v[t] + 4) = *reinterpret_cast<const f32x4*>(xr + ch * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[t][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int ch = lane + 64 * t;
+    if (ch < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float d = v[t][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int ch = lane + 64 * t;
+    if (ch < nch) {
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (v[t][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+      if (HL) store_hl32_8(out_hl + (size_t)row * C * 4, ch * 8, y);
+      else {
+        *reinterpret_cast<f32x4*>(out_f + row * C + ch * 8) = *reinterpret_cast<f32x4*>(y);
+        *reinterpret_cast<f32x4*>(out_f + row * C + ch * 8 + 4) = *reinterpret_cast<f32x4*>(y + 4);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------ GEMM epilogues
+// q,k: rows = tokens (b*T + t), cols in [0, 2C): dest hl32 [which][B*H][Tpad][64]
+struct EpiQK {
+  const float* bias; uint8_t* q; uint8_t* k; int M, C, T, Tpad, H;
+  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n_wave + ni * 32 + r;          // 32-aligned group: one (which, head, half-of-head)
+      if (col >= 2 * C) continue;
+      const int which = col / C, fcol = col - which * C, head = fcol >> 6, d = fcol & 63;
+      uint8_t* base = (which ? k : q);
+      const float bc = bias[col];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < M) {
+            int b = row / T, t = row - b * T;
+            float v = f.acc[mi][ni][i] + bc;
+            _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            uint8_t* p = base + (((size_t)b * H + head) * Tpad + t) * (HD * 4) + (d >> 5) * 128 + (d & 31) * 2;
+            *reinterpret_cast<_Float16*>(p) = hi;
+            *reinterpret_cast<_Float16*>(p + 64) = lo;
+          }
+        }
+    }
+  }
+};
+
+// v, transposed: rows = v feature (head*64 + d) on the registers, cols = tokens on the lanes:
+// dest hl32 [B*H][64][Tpad] (K axis = token), so consecutive lanes write consecutive halves.
+struct EpiVt {
+  const float* bias; uint8_t* vt; int C, NT, T, Tpad, H;   // bias already offset to the v third
+  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n_wave + ni * 32 + r;
+      if (col >= NT) continue;
+      const int b = col / T, t = col - b * T;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < C) {
+            int head = row >> 6, d = row & 63;
+            float v = f.acc[mi][ni][i] + bias[row];
+            _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            uint8_t* p = vt + (((size_t)b * H + head) * HD + d) * ((size_t)Tpad * 4) + (t >> 5) * 128 + (t & 31) * 2;
+            *reinterpret_cast<_Float16*>(p) = hi;
+            *reinterpret_cast<_Float16*>(p + 64) = lo;
+          }
+        }
+    }
+  }
+};
+
+// out[m][col] = acc + bias[col] + res[m][col]   (fp32; out may alias res)
+struct EpiResidual {
+  const float* bias; const float* res; float* out; int M, N;
+  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n_wave + ni * 32 + r;
+      if (col >= N) continue;
+      const float bc = bias[col];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < M) {
+            size_t o = (size_t)row * N + col;
+            out[o] = res[o] + (f.acc[mi][ni][i] + bc);
+          }
+        }
+    }
+  }
+};
+
+// g = gelu(acc + bias) (exact erf form, nn.GELU default) -> hl32 [M, N]
+struct EpiGeluHl {
+  const float* bias; uint8_t* out; int M, N;
+  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n_wave + ni * 32 + r;
+      if (col >= N) continue;
+      const float bc = bias[col];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (row < M) {
+            float v = f.acc[mi][ni][i] + bc;
+            v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+            uint8_t* p = out + (size_t)row * N * 4 + (col >> 5) * 128 + (col & 31) * 2;
+            *reinterpret_cast<_Float16*>(p) = hi;
+            *reinterpret_cast<_Float16*>(p + 64) = lo;
+          }
+        }
+    }
+  }
+};
+
+// ----------------------------------------------------------------- attention
+// softmax(q k^T * scale) v for one (image, head), flash style, split-fp16 MFMA for both products.
+// Swapped orientation: S^T = K Q^T puts the KEYS on the accumulator registers and the QUERY on
+// the lane, so the softmax max/sum over keys are in-lane reductions plus one lane-half exchange,
+// and the exponentiated tile is already laid out as the B operand of O^T += V^T P^T
+// (accumulator-as-operand, k order 16s + 8(j>>2) + 4h + (j&3); V^T fragments are read in that order).
+// Block = 4 waves x 32 queries; K and V^T tiles of 32 keys are staged once per block in LDS.
+constexpr int ATT_Q = 128, ATT_KT = 32;
+constexpr int ATT_LDS = 4 * 32 * 65 * 4;   // epilogue transpose buffer (>= 16 KB of K/V tiles)
+
+__global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ K,
+                                                        const uint8_t* __restrict__ Vt, uint8_t* __restrict__ O,
+                                                        int T, int Tpad, int H, float scale) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[ATT_LDS];
+  uint8_t* Ks = lds;             // [32 keys][256 B], 16-B slots XOR (row & 15)
+  uint8_t* Vs = lds + 8192;      // [64 d][128 B],   16-B slots XOR ((row >> 1) & 7)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+  const int q0 = blockIdx.x * ATT_Q + wave * 32;
+  const int C = H * HD;
+
+  // Q fragments (B operand): lane = query column, element j <-> feature 16s + 8h + j
+  half8 qh[4], ql[4];
+  {
+    const uint8_t* qrow = Q + ((size_t)bh * Tpad + min(q0 + r, T - 1)) * (HD * 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint8_t* p = qrow + (s >> 1) * 128 + (s & 1) * 32 + h * 16;
+      qh[s] = *reinterpret_cast<const half8*>(p);
+      ql[s] = *reinterpret_cast<const half8*>(p + 64);
+    }
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m_run = -__builtin_inff(), l_run = 0.f;
+
+  const uint8_t* Kbase = K + (size_t)bh * Tpad * (HD * 4);
+  const uint8_t* Vbase = Vt + (size_t)bh * HD * ((size_t)Tpad * 4);
+  const int ntiles = (T + ATT_KT - 1) / ATT_KT;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * ATT_KT;
+    __syncthreads();                       // previous tile fully consumed
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      int row = (tid >> 4) + rep * 16, slot = tid & 15;
+      u32x4 v = *reinterpret_cast<const u32x4*>(Kbase + (size_t)(key0 + row) * (HD * 4) + slot * 16);
+      *reinterpret_cast<u32x4*>(Ks + row * 256 + ((slot ^ (row & 15)) << 4)) = v;
+      int vrow = (tid >> 3) + rep * 32, vslot = tid & 7;
+      u32x4 w = *reinterpret_cast<const u32x4*>(Vbase + (size_t)vrow * ((size_t)Tpad * 4) + (size_t)kt * 128 + vslot * 16);
+      *reinterpret_cast<u32x4*>(Vs + vrow * 128 + ((vslot ^ ((vrow >> 1) & 7)) << 4)) = w;
+    }
+    __syncthreads();
+
+    // S^T tile [32 keys x 32 queries]
+    f32x16 s_acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int slot = (s >> 1) * 8 + (s & 1) * 2 + h;
+      half8 kh = *reinterpret_cast<const half8*>(Ks + r * 256 + ((slot ^ (r & 15)) << 4));
+      half8 kl = *reinterpret_cast<const half8*>(Ks + r * 256 + (((slot + 4) ^ (r & 15)) << 4));
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s_acc, 0, 0, 0);
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s_acc, 0, 0, 0);
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s_acc, 0, 0, 0);
+    }
+    // online softmax over the key axis (registers + the other lane half)
+    float sv[16];
+    float mloc = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      sv[i] = key < T ? s_acc[i] * scale : -__builtin_inff();
+      mloc = fmaxf(mloc, sv[i]);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float corr = expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    half8 ph[2], pl[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float p = expf(sv[i] - m_new);
+      psum += p;
+      _Float16 hi = (_Float16)p;
+      ph[i >> 3][i & 7] = hi;
+      pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
+    }
+    l_run = l_run * corr + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= corr; o[1][i] *= corr; }
+    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8(j>>2) + 4h + (j&3)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int d = mt * 32 + r, sw = (d >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int g0 = 4 * s + h, g1 = g0 + 2;                 // 8-byte granules of the hi part
+        half4 a0 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g0 >> 1) ^ sw) << 4) + (g0 & 1) * 8);
+        half4 a1 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g1 >> 1) ^ sw) << 4) + (g1 & 1) * 8);
+        half4 b0 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((((g0 + 8) >> 1) ^ sw) << 4) + (g0 & 1) * 8);
+        half4 b1 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((((g1 + 8) >> 1) ^ sw) << 4) + (g1 & 1) * 8);
+        half8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[mt], 0, 0, 0);
+        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[mt], 0, 0, 0);
+      }
+    }
+  }
+  // normalise, transpose through LDS ([32 q][65] floats per wave), write hl32 lines
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  __syncthreads();
+  float* tb = reinterpret_cast<float*>(lds) + wave * 32 * 65;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tb[r * 65 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = o[mt][i] * inv;
+  __builtin_amdgcn_s_waitcnt(0);   // LDS writes of this wave are visible to itself after lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  const int q = lane >> 1, half = lane & 1, tq = q0 + q;
+  if (tq < T) {
+    const float* src = tb + q * 65 + half * 32;
+    uint8_t* dst = O + ((size_t)b * T + tq) * ((size_t)C * 4) + (head * 2 + half) * 128;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[c8 * 8 + j];
+      half8 hi, lo;
+      split8(v, hi, lo);
+      *reinterpret_cast<half8*>(dst + c8 * 16) = hi;
+      *reinterpret_cast<half8*>(dst + 64 + c8 * 16) = lo;
+    }
+  }
+}
+
+// zero the pad columns t in [T, Tpad) of every V^T row (p = 0 there, but 0 * garbage must stay 0)
+__global__ void zero_vt_pad_kernel(uint8_t* vt, int rows, int T, int Tpad) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int npad = Tpad - T;
+  if (i >= rows * npad) return;
+  int row = i / npad, t = T + (i - row * npad);
+  uint8_t* p = vt + (size_t)row * Tpad * 4 + (t >> 5) * 128 + (t & 31) * 2;
+  *reinterpret_cast<_Float16*>(p) = (_Float16)0.f;
+  *reinterpret_cast<_Float16*>(p + 64) = (_Float16)0.f;
+}
+
+// -------------------------------------------------------------------- C ABI
+struct VitWs {
+  uint8_t *h, *q, *k, *vt, *o, *g, *cols;
+};
+
+static size_t vit_ws_carve(Arena& ar, int B, int T, int C, int hidden, int heads, int patch_dim, VitWs* w) {
+  const size_t M = (size_t)B * T, Tp = tpad_of(T);
+  VitWs t;
+  t.h = ar.take<uint8_t>(M * C * 4);
+  t.q = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
+  t.k = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
+  t.vt = ar.take<uint8_t>((size_t)B * heads * HD * Tp * 4);
+  t.o = ar.take<uint8_t>(M * C * 4);
+  t.g = ar.take<uint8_t>(M * (size_t)hidden * 4);
+  t.cols = ar.take<uint8_t>(M * (size_t)patch_dim * 4);
+  if (w) *w = t;
+  return ar.off;
+}
+
+extern "C" size_t ac_vit_workspace_bytes(int B, int T, int C, int hidden, int heads, int patch_dim) {
+  if (B <= 0 || T <= 0 || C <= 0 || hidden <= 0 || heads <= 0 || patch_dim <= 0) return 256;
+  Arena ar(nullptr, ~(size_t)0 >> 1);
+  return vit_ws_carve(ar, B, T, C, hidden, heads, patch_dim, nullptr) + 256;
+}
+
+extern "C" int ac_vit_prepare_tokens(const float* images, int B, int in_ch, int img, int patch, int C,
+                                     const void* proj_w, const float* proj_b, const float* cls, const float* pos,
+                                     float* x, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(images && proj_w && proj_b && cls && pos && x && ws, "ac_vit_prepare_tokens: null pointer");
+  AC_REQUIRE(B > 0 && in_ch > 0 && patch > 0 && img % patch == 0, "ac_vit_prepare_tokens: bad geometry");
+  AC_REQUIRE(patch % 8 == 0, "ac_vit_prepare_tokens: patch=%d must be a multiple of 8", patch);
+  const int G = img / patch, PP = G * G, T = PP + 1, Kd = in_ch * patch * patch;
+  AC_REQUIRE(Kd % 32 == 0, "ac_vit_prepare_tokens: in_ch*patch^2=%d must be a multiple of 32", Kd);
+  size_t need = align_up((size_t)B * PP * Kd * 4, 256);
+  if (ws_bytes < need) return ac_fail(AC_EWORKSPACE, "ac_vit_prepare_tokens: workspace %zu < %zu", ws_bytes, need);
+  uint8_t* cols = static_cast<uint8_t*>(ws);
+  size_t chunks = (size_t)B * PP * (Kd / 8);
+  hipLaunchKernelGGL(im2col_hl_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, images, B, in_ch,
+                     img, patch, cols);
+  hipLaunchKernelGGL(set_cls_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, cls, pos, B, T, C, x);
+  EpiPatchEmbed epi{proj_b, pos, x, B * PP, C, PP, T};
+  return gemm::launch(cols, proj_w, B * PP, C, Kd, epi, stream);
+}
+
+extern "C" int ac_layernorm_rows(const float* x, int64_t rows, int C, const float* w, const float* b, float eps,
+                                 float* y, void* stream) {
+  AC_REQUIRE(x && w && b && y, "ac_layernorm_rows: null pointer");
+  AC_REQUIRE(C > 0 && C % 8 == 0 && C <= 2048, "ac_layernorm_rows: C=%d must be a multiple of 8, <= 2048", C);
+  if (rows <= 0) return AC_OK;
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, rows,
+                     C, w, b, eps, (uint8_t*)nullptr, y);
+  return ac_check_launch("layernorm_rows");
+}
+
+extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float* x_out, int B, int T, int C, int heads,
+                            int hidden, float eps, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(w && x_in && x_out && ws, "ac_vit_block: null pointer");
+  AC_REQUIRE(B > 0 && T > 0, "ac_vit_block: empty batch");
+  AC_REQUIRE(heads > 0 && C == heads * HD, "ac_vit_block: C=%d must equal heads*64 (heads=%d)", C, heads);
+  AC_REQUIRE(C % 32 == 0 && hidden % 32 == 0 && C <= 2048, "ac_vit_block: C, hidden must be multiples of 32; C <= 2048");
+  AC_REQUIRE((long long)B * T < (1LL << 30), "ac_vit_block: too many tokens");
+  if (ws_bytes < ac_vit_workspace_bytes(B, T, C, hidden, heads, 32))
+    return ac_fail(AC_EWORKSPACE, "ac_vit_block: workspace %zu < %zu", ws_bytes,
+                   ac_vit_workspace_bytes(B, T, C, hidden, heads, 32));
+  Arena ar(ws, ws_bytes);
+  VitWs b;
+  vit_ws_carve(ar, B, T, C, hidden, heads, 32, &b);
+  if (!ar.ok()) return ac_fail(AC_EWORKSPACE, "ac_vit_block: workspace carve failed");
+  const int M = B * T, Tp = tpad_of(T);
+  const unsigned ln_grid = (unsigned)((M + 3) / 4);
+  int rc;
+
+  // x_mid = x_in + proj(attn(ln1(x_in)))
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3(ln_grid), dim3(256), 0, stream, x_in, (int64_t)M, C, w->ln1_w, w->ln1_b,
+                     eps, b.h, (float*)nullptr);
+  const uint8_t* wqkv = static_cast<const uint8_t*>(w->qkv_w);
+  EpiQK eqk{w->qkv_b, b.q, b.k, M, C, T, Tp, heads};
+  if ((rc = gemm::launch(b.h, wqkv, M, 2 * C, C, eqk, stream))) return rc;
+  EpiVt evt{w->qkv_b + 2 * C, b.vt, C, M, T, Tp, heads};
+  if ((rc = gemm::launch(wqkv + (size_t)2 * C * C * 4, b.h, C, M, C, evt, stream))) return rc;
+  if (Tp > T) {
+    int n = B * heads * HD * (Tp - T);
+    hipLaunchKernelGGL(zero_vt_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b.vt, B * heads * HD, T, Tp);
+  }
+  hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.vt,
+                     b.o, T, Tp, heads, 1.0f / sqrtf((float)HD));
+  EpiResidual ep{w->proj_b, x_in, x_out, M, C};
+  if ((rc = gemm::launch(b.o, w->proj_w, M, C, C, ep, stream))) return rc;
+
+  // x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3(ln_grid), dim3(256), 0, stream, x_out, (int64_t)M, C, w->ln2_w,
+                     w->ln2_b, eps, b.h, (float*)nullptr);
+  EpiGeluHl eg{w->fc1_b, b.g, M, hidden};
+  if ((rc = gemm::launch(b.h, w->fc1_w, M, hidden, C, eg, stream))) return rc;
+  EpiResidual e2{w->fc2_b, x_out, x_out, M, C};
+  if ((rc = gemm::launch(b.g, w->fc2_w, M, C, hidden, e2, stream))) return rc;
+  return ac_check_launch("ac_vit_block");
+}

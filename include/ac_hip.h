@@ -1,0 +1,149 @@
+/* ac_hip.h - C ABI of the MI355X (gfx950) anomaly-clustering hot path.
+ *
+ * The reference (KevinWangHP/Anomaly-Clustering) has no FFI: its boundary is the
+ * Python call surface used by examples/main.py and examples/test.py.  This
+ * library sits *under* that surface: every entry point below replaces the
+ * arithmetic of one reference function (cited per function, paths relative to
+ * Anomaly-Clustering/), and the `patchcore` package under anomaly-clustering_amd/models/ keeps
+ * the reference's Python signatures on top of it (INTEGRATION.md shows the
+ * ctypes stubs a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers + sizes + an opaque HIP stream
+ *     (`void* stream` is a hipStream_t; NULL = the null stream).
+ *   - no allocation, no synchronisation, no global state inside: the caller owns
+ *     every buffer, including the scratch `ws` whose size the matching
+ *     *_workspace_bytes() returns.  All pointers are DEVICE pointers unless a
+ *     parameter says "host".
+ *   - returns AC_OK (0) or an AC_E* code; ac_last_error() gives the message of
+ *     the calling thread's last failure.
+ *   - "hl32" = the split-fp16 operand format of the MFMA kernels: a [rows, K]
+ *     fp32 matrix stored as rows of K*4 bytes, each 128-byte group holding 32
+ *     high halves (fp16(x)) followed by the 32 low halves (fp16(x - hi)) of the
+ *     same 32 columns.  hi+lo carries 22 significand bits, and the 3-pass
+ *     product hi*hi + hi*lo + lo*hi accumulated in fp32 by
+ *     v_mfma_f32_32x32x16_f16 is at least as accurate as an fp32 FMA chain
+ *     (measured: profiles/r01_mfma_probe.txt).
+ */
+#ifndef AC_HIP_H
+#define AC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_OK 0
+#define AC_EINVAL 1     /* bad shape / alignment / null pointer */
+#define AC_EWORKSPACE 2 /* workspace too small */
+#define AC_ELAUNCH 3    /* HIP reported a launch error */
+
+int ac_version(void);
+const char* ac_last_error(void);
+
+/* ------------------------------------------------------------------ operands */
+
+/* fp32 [rows, K] (row stride `src_ld` floats) -> hl32 [rows, K]; K % 32 == 0.
+ * row_sqnorm (nullable): fp32 [rows] = sum_k src[r][k]^2 (fp64 accumulation, rounded once).
+ * Used for: weight matrices at model load; Z inside ac_pair_min_dist. */
+int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_ld, void* dst_hl32,
+                 float* row_sqnorm, void* stream);
+
+/* ----------------------------------------------------------------------- ViT */
+
+/* Weights of one transformer block, reference models/patchcore/vision_transformer.py:95-113.
+ * Matrices are hl32 copies of the torch [out, in] weights. */
+typedef struct ac_block_weights {
+  const float* ln1_w; const float* ln1_b;          /* [C] */
+  const void* qkv_w; const float* qkv_b;           /* hl32 [3C, C], [3C] */
+  const void* proj_w; const float* proj_b;         /* hl32 [C, C], [C] */
+  const float* ln2_w; const float* ln2_b;          /* [C] */
+  const void* fc1_w; const float* fc1_b;           /* hl32 [Hd, C], [Hd] */
+  const void* fc2_w; const float* fc2_b;           /* hl32 [C, Hd], [C] */
+} ac_block_weights;
+
+/* Scratch for ac_vit_prepare_tokens / ac_vit_block at batch B. */
+size_t ac_vit_workspace_bytes(int B, int T, int C, int hidden, int heads, int patch_dim);
+
+/* VisionTransformer.prepare_tokens (vision_transformer.py:196-207) + PatchEmbed (:128-131):
+ * images fp32 [B, in_ch, img, img] (NCHW) -> x fp32 [B, T, C], T = (img/patch)^2 + 1.
+ * proj_w: hl32 [C, in_ch*patch*patch] (the conv weight flattened (c,ky,kx)); cls [C]; pos [T, C]. */
+int ac_vit_prepare_tokens(const float* images, int B, int in_ch, int img, int patch, int C,
+                          const void* proj_w, const float* proj_b, const float* cls, const float* pos,
+                          float* x, void* ws, size_t ws_bytes, void* stream);
+
+/* Block.forward (vision_transformer.py:107-113): x_out = x + attn(ln1(x)); x_out += mlp(ln2(x_out)).
+ * x_in, x_out: fp32 [B, T, C]; may alias.  head_dim must be 64; C % 64 == 0; hidden % 128 == 0. */
+int ac_vit_block(const ac_block_weights* w /* host struct of device pointers */, const float* x_in,
+                 float* x_out, int B, int T, int C, int heads, int hidden, float eps, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* nn.LayerNorm over the last dim of fp32 [rows, C] (final `norm`, vision_transformer.py:213). */
+int ac_layernorm_rows(const float* x, int64_t rows, int C, const float* w, const float* b, float eps,
+                      float* y, void* stream);
+
+/* --------------------------------------------------------- patch aggregation */
+
+#define AC_FEAT_TOKENS 0 /* [B, 1+H*W, C] token map, CLS first (ViT) */
+#define AC_FEAT_NCHW 1   /* [B, C, H, W] (CNN backbones) */
+
+size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C, const int* H, const int* W, int B,
+                                          int patchsize, int pre_dim, int tgt_dim);
+
+/* AnomalyClusteringCore._embed after the backbone (models/patchcore/patchcore.py:375-427),
+ * PatchMaker.patchify (:439-465), Preprocessing/MeanMapper (models/patchcore/common.py:145-170),
+ * Aggregator (common.py:173-183):
+ *   per layer: drop CLS -> standardise over (C,H,W) per image (eps) -> zero-padded k x k unfold
+ *   (stride 1) -> bilinear resize of the patch grid to layer 0's grid -> adaptive_avg_pool1d
+ *   (C*k*k -> pre_dim); concat layers -> adaptive_avg_pool1d (n_layers*pre_dim -> tgt_dim).
+ * feats: host array of n_layers device pointers; kind/C/H/W: host int arrays.
+ * Z: fp32 [B * H0*W0, tgt_dim]. */
+int ac_patch_aggregate(const float* const* feats, const int* kind, const int* C, const int* H,
+                       const int* W, int n_layers, int B, int patchsize, int pre_dim, int tgt_dim,
+                       float eps, float* Z, void* ws, size_t ws_bytes, void* stream);
+
+/* The pieces of the chain above as separate operators, for callers that use the reference's
+ * modules one by one (PatchMaker.patchify, MeanMapper.forward, Aggregator.forward): */
+
+/* torch.nn.Unfold(k, stride 1, pad (k-1)/2) + reshape/permute of patchcore.py:447-461:
+ * x fp32 [B, C, H, W] -> out fp32 [B, H*W, C, k, k] (zero padded). k odd. */
+int ac_unfold_patches(const float* x, int B, int C, int H, int W, int patchsize, float* out, void* stream);
+
+/* F.adaptive_avg_pool1d over the last axis (common.py:168-170, 181-182):
+ * x fp32 [rows, L] -> y fp32 [rows, O]; window [floor(i*L/O), ceil((i+1)*L/O)), fp32 sum / length. */
+int ac_adaptive_avg_pool_rows(const float* x, int64_t rows, int L, int O, float* y, void* stream);
+
+/* --------------------------------------------------------------------- alpha */
+
+#define AC_REDUCE_MEAN_OTHERS 0 /* unsupervised: mean over key images j != self (utils.py:222-227) */
+#define AC_REDUCE_MIN_ALL 1     /* supervised:   min over all key images     (utils.py:230-237) */
+
+size_t ac_pair_min_dist_workspace_bytes(int64_t nq, int64_t nk, int P, int D);
+
+/* Weight_Distance_{Unsupervised,Supervised} for a block of query images (models/patchcore/utils.py:222-237):
+ *   w[i][p] = reduce_j  min_q || Zq[i][p] - Zk[j][q] ||_2
+ * Zq fp32 [nq, P, D], Zk fp32 [nk, P, D] (may be the same buffer), D % 32 == 0.
+ * MEAN_OTHERS skips key image j == i + self_offset (the query's own image in the key list) and
+ * divides by the number of remaining images.  w: fp32 [nq, P]. */
+int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, int P, int D, int reduce,
+                     int64_t self_offset, float* w, void* ws, size_t ws_bytes, void* stream);
+
+/* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
+ *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;
+ *   else alpha = k*exp(w/tau) / sum, computed max-shifted (same value, no overflow).
+ * w fp32 [N, P] -> alpha fp64 [N, P]. */
+int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, void* stream);
+
+/* examples/main.py:294-296: X[i] = alpha[i] (fp32 [P]) . Z[i] (fp32 [P, D]) -> fp32 [N, D]. */
+int ac_weighted_avg(const float* alpha, const float* Z, int64_t N, int P, int D, float* X, void* stream);
+
+/* scipy pdist(euclidean) as used by Ward linkage (examples/test.py:193-195 via sklearn/scipy):
+ * X fp32 [N, D] -> condensed fp64 [N*(N-1)/2], each distance accumulated in fp64 from fp64 differences. */
+int ac_pdist(const float* X, int64_t N, int D, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AC_HIP_H */

@@ -1,0 +1,88 @@
+"""GPU parity: fused patch-aggregation kernel vs vectors captured from the reference's
+AnomalyClusteringCore._embed (tests/golden/aggregate_*.npz) and vs the oracle.
+
+Tolerance: Z is a mean of 4-5 standardised fp32 values (|Z| <~ 4): |Z - ref| <= 3e-6 + 2e-6*|ref|
+(differences come only from the mean/rstd rounding of the per-image standardisation).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _synth import gaussish_tensor
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 3e-6, 2e-6
+
+
+def _close(a, ref):
+    err = np.abs(a - ref)
+    ok = np.all(err <= ATOL + RTOL * np.abs(ref))
+    return ok, err.max()
+
+
+@pytest.mark.parametrize("tag,salts,shape_a,shape_b,off", [
+    ("tok_small", (21, 22), (2, 37, 64), (2, 37, 64), (0.3, -0.1)),
+    ("tok_p5", (21, 22), (2, 37, 64), (2, 37, 64), (0.3, -0.1)),
+    ("cnn_small", (23, 24), (2, 32, 12, 12), (2, 48, 6, 6), (0.0, 0.0)),
+])
+def test_variants_against_reference_golden(golden, dev, tag, salts, shape_a, shape_b, off):
+    import acnative
+    g = golden("aggregate_%s.npz" % tag)
+    scales = {"tok_small": (2.0, 1.0), "tok_p5": (2.0, 1.0), "cnn_small": (2.0, 1.5)}[tag]
+    fa = torch.from_numpy(gaussish_tensor(shape_a, salt=salts[0], scale=scales[0])) + off[0]
+    fb = torch.from_numpy(gaussish_tensor(shape_b, salt=salts[1], scale=scales[1])) + off[1]
+    Z, grids = acnative.patch_aggregate([fa.to(dev), fb.to(dev)], int(g["patchsize"]), int(g["pre"]), int(g["tgt"]))
+    ok, mx = _close(Z.cpu().numpy(), g["Z"])
+    print(tag, "max err %.3e" % mx, grids)
+    assert Z.shape == g["Z"].shape and ok
+
+
+def test_wrn50_shaped_cnn_branch(golden, dev):
+    """BASELINE config 1's shapes: layer2 [512,28,28] + layer3 [1024,14,14] (bilinear 14->28), 1024->1024."""
+    import acnative
+    g = golden("aggregate_wrn.npz")
+    wa = torch.from_numpy(gaussish_tensor((1, 512, 28, 28), salt=25, scale=2.0))
+    wb = torch.from_numpy(gaussish_tensor((1, 1024, 14, 14), salt=26, scale=1.0))
+    Z, grids = acnative.patch_aggregate([wa.to(dev), wb.to(dev)], 3, 1024, 1024)
+    Zc = Z.cpu().numpy()
+    ok, mx = _close(Zc[g["rows"]], g["Z_rows"])
+    print("wrn max err %.3e" % mx)
+    assert ok and grids == [[28, 28], [14, 14]]
+    np.testing.assert_allclose(Zc.astype(np.float64).sum(1), g["Z_rowsum"], rtol=0, atol=2e-3)
+
+
+def test_vit_shaped_against_oracle_full(dev):
+    """[B,785,768] x 2 layers, 3x3, 2048 -> 4096: the headline configuration, every element."""
+    import acnative
+    from oracle import aggregate as oagg
+    f10 = torch.from_numpy(gaussish_tensor((2, 785, 768), salt=81, scale=3.0)) + 0.2
+    f11 = torch.from_numpy(gaussish_tensor((2, 785, 768), salt=82, scale=5.0)) - 0.4
+    ref, rgrids = oagg.aggregate([f10, f11], 3, 2048, 4096)
+    Z, grids = acnative.patch_aggregate([f10.to(dev), f11.to(dev)], 3, 2048, 4096)
+    ok, mx = _close(Z.cpu().numpy(), ref.numpy())
+    print("vit-shaped max err %.3e" % mx)
+    assert ok and grids == rgrids and Z.shape == (2 * 784, 4096)
+
+
+def test_standalone_unfold_and_pool_vs_oracle(dev):
+    import acnative
+    from oracle import aggregate as oagg
+    x = torch.from_numpy(gaussish_tensor((2, 5, 7, 6), salt=83))
+    ref, grid = oagg.patchify(x, 3)
+    got = acnative.unfold_patches(x.to(dev), 3).cpu()
+    assert torch.equal(got, ref.contiguous())
+    rows = torch.from_numpy(gaussish_tensor((9, 6912), salt=84))
+    for out in (2048, 1000, 6912, 7000):
+        ref = oagg.mean_map(rows, out)
+        got = acnative.adaptive_pool_rows(rows.to(dev), out).cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_adaptive_windows_match_survey():
+    from oracle.aggregate import adaptive_windows
+    s, e = adaptive_windows(6912, 2048)
+    widths = e - s
+    assert (widths == 4).sum() == 1536 and (widths == 5).sum() == 512
+    s2, e2 = adaptive_windows(4096, 4096)
+    assert np.array_equal(e2 - s2, np.ones(4096, dtype=np.int64))          # identity at 2*2048 -> 4096
