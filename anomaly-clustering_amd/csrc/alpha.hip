@@ -183,6 +183,28 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
   return ac_check_launch("ac_pair_min_dist");
 }
 
+// Staged form of the same computation (pack -> min-d2 GEMM -> reduce) for callers that keep the
+// packed operands resident across calls or want to time the MFMA kernel on its own.
+extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64_t nk, const void* Zq_hl,
+                                     const float* q_sq, int64_t nq, int P, int D, uint32_t* minbuf, void* stream) {
+  AC_REQUIRE(Zk_hl && k_sq && Zq_hl && q_sq && minbuf, "ac_pair_min_sq_packed: null pointer");
+  AC_REQUIRE(nq > 0 && nk > 0 && P > 0 && D > 0 && D % 32 == 0, "ac_pair_min_sq_packed: bad shape");
+  AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_sq_packed: too many patches");
+  EpiPairMin epi{k_sq, q_sq, minbuf, (int)(nk * P), (int)(nq * P), P};
+  return gemm::launch(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), 16);
+}
+
+extern "C" int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,
+                              float* w, void* stream) {
+  AC_REQUIRE(minbuf && w, "ac_pair_reduce: null pointer");
+  AC_REQUIRE(nq > 0 && nk > 0 && P > 0, "ac_pair_reduce: bad shape");
+  AC_REQUIRE(reduce == AC_REDUCE_MEAN_OTHERS || reduce == AC_REDUCE_MIN_ALL, "ac_pair_reduce: bad reduce=%d", reduce);
+  int64_t N = nq * P;
+  hipLaunchKernelGGL(reduce_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), minbuf, nk,
+                     N, P, reduce, self_first, w);
+  return ac_check_launch("ac_pair_reduce");
+}
+
 // ------------------------------------------------------------ alpha softmax
 // One block per image.  fp64 throughout (utils.py:245, 253-254): alpha = k*exp(w/tau)/sum.
 // The max is subtracted before exp - mathematically identical, and finite where the

@@ -45,6 +45,8 @@ SIGNATURES = {
     "ac_adaptive_avg_pool_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "ac_pair_min_dist_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
     "ac_pair_min_dist": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
+    "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "ac_pair_reduce": (_i, [_vp, _i64, _i64, _i, _i, _i64, _vp, _vp]),
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
@@ -265,6 +267,46 @@ def pair_min_dist(Zq, Zk, reduce, self_offset=0):
     w = torch.empty((nq, P), dtype=torch.float32, device=Zq.device)
     _check(lib().ac_pair_min_dist(pq, nq, pq if same else pk, nk, P, D, reduce, self_offset, w.data_ptr(),
                                   ws.data_ptr(), nbytes, _stream()))
+    return w
+
+
+kernel_events = None   # set to a list to collect (label, start, stop) torch events around MFMA launches
+
+
+def pair_min_dist_staged(Zq, Zk, reduce, self_offset=0, minbuf_budget=1 << 30):
+    """Same result as pair_min_dist, composed from the staged entry points (pack once, one MFMA
+    launch per query chunk, reduce).  When `kernel_events` is a list, each MFMA launch is bracketed
+    by events recorded on the launch stream (bench.py's roofline leg reads them)."""
+    pq, pk = _dev(Zq, torch.float32, "Zq"), _dev(Zk, torch.float32, "Zk")
+    nq, P, D = Zq.shape
+    nk = Zk.shape[0]
+    if Zk.shape[1:] != Zq.shape[1:]:
+        raise ValueError("Zq / Zk patch shapes differ: %s vs %s" % (tuple(Zq.shape), tuple(Zk.shape)))
+    hk, sk = pack_hl32(Zk.reshape(nk * P, D), want_sqnorm=True)
+    if pq == pk and nq == nk:
+        hq, sq = hk, sk
+    elif pk <= pq < pk + Zk.numel() * 4 and (pq - pk) % (P * D * 4) == 0 and pq + Zq.numel() * 4 <= pk + Zk.numel() * 4:
+        first = (pq - pk) // (P * D * 4)                      # the query shard is a slice of the key set
+        hq, sq = hk[first * P:(first + nq) * P], sk[first * P:(first + nq) * P]
+    else:
+        hq, sq = pack_hl32(Zq.reshape(nq * P, D), want_sqnorm=True)
+    chunk = max(1, min(nq, minbuf_budget // (nk * P * 4)))
+    w = torch.empty((nq, P), dtype=torch.float32, device=Zq.device)
+    minbuf = torch.empty((nk, chunk * P), dtype=torch.int32, device=Zq.device)
+    st = _stream()
+    for q0 in range(0, nq, chunk):
+        qn = min(chunk, nq - q0)
+        mb = minbuf.view(-1)[: nk * qn * P]
+        mb.fill_(0x7f800000)
+        if kernel_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _check(lib().ac_pair_min_sq_packed(hk.data_ptr(), sk.data_ptr(), nk, hq[q0 * P:].data_ptr(),
+                                           sq[q0 * P:].data_ptr(), qn, P, D, mb.data_ptr(), st))
+        if kernel_events is not None:
+            ev1.record()
+            kernel_events.append(("pair_min_sq", ev0, ev1, nk, qn, P, D))
+        _check(lib().ac_pair_reduce(mb.data_ptr(), nk, qn, P, reduce, self_offset + q0, w[q0:].data_ptr(), st))
     return w
 
 

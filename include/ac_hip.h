@@ -130,6 +130,18 @@ size_t ac_pair_min_dist_workspace_bytes(int64_t nq, int64_t nk, int P, int D);
 int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, int P, int D, int reduce,
                      int64_t self_offset, float* w, void* ws, size_t ws_bytes, void* stream);
 
+/* The same computation in stages, for callers that keep packed operands resident (multi-GPU
+ * shards, tau sweeps) or time the MFMA kernel alone:
+ *   ac_pack_hl32(Z, rows = n*P, K = D, ..., row_sqnorm)            -> Z_hl, sq
+ *   ac_pair_min_sq_packed: minbuf[j][i*P + p] = min(minbuf, min_q d2(Zq[i][p], Zk[j][q])) as the
+ *       IEEE bits of a non-negative float; the caller presets minbuf (uint32 [nk][nq*P]) to +inf
+ *       (0x7f800000).  This call launches exactly one kernel (the MFMA GEMM with the fused min).
+ *   ac_pair_reduce: w[i][p] = mean_{j != self_first + i} sqrt(minbuf[j][..]) or sqrt(min_j ..). */
+int ac_pair_min_sq_packed(const void* Zk_hl32, const float* k_sqnorm, int64_t nk, const void* Zq_hl32,
+                          const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, void* stream);
+int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,
+                   float* w, void* stream);
+
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
  *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;
  *   else alpha = k*exp(w/tau) / sum, computed max-shifted (same value, no overflow).

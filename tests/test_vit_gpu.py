@@ -70,7 +70,7 @@ def test_batch_not_multiple_of_anything_and_hooks(dev):
     model = _model(dev, depth=2)
     images = torch.from_numpy(gaussish_tensor((3, 3, 224, 224), salt=12, scale=1.2))
     agg = common.NetworkFeatureAggregator(model, ["blocks.0", "blocks.1"], dev)
-    feats = agg(images.to(dev))
+    feats = dict(agg(images.to(dev)))      # copy: the aggregator reuses (and clears) its output dict, as upstream
     assert set(feats) == {"blocks.0", "blocks.1"} and feats["blocks.1"].shape == (3, 785, 768)
     assert agg.feature_dimensions((3, 224, 224)) == [785, 785]
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
