@@ -1,0 +1,182 @@
+"""alpha + X producer (drop-in for the reference's examples/main.py:183-366).
+
+Same flags and defaults as the reference (--path --backbone_names --layers_to_extract_from
+--pretrain_embed_dimension --target_embed_dimension --output_dir --patchsize --tau --train_ratio
+--supervised --dataset), the same artefact: ``torch.save((alpha FloatTensor[N,1,P], X float32
+ndarray[N,D]))`` under
+``{output_dir}/{dataset}/{backbone}/{mode}/{layers}_{pre}_{tgt}_{float(tau)}_{float(ratio)}/
+matrix_alpha_X_{category}_{mode}.pickle``, plus ``{output_dir}/{dataset}/info/info_{category}.pickle``
+(the reference's writer is commented out at main.py:263 although test.py:156 needs the file).
+
+Conscious differences:
+  * --supervised selects the mode (reference overrides it with a hard-coded loop over both,
+    main.py:348); ``--supervised both`` reproduces the reference's behaviour.
+  * ``--dataset synthetic`` (or a missing --path) uses MVTec-AD-shaped synthetic images.
+  * images are embedded in batches and stay on the device; the normal-image bank of the
+    supervised mode is a seeded permutation (reference: unseeded shuffle, main.py:274).
+  * launched under torchrun, the images of each category are sharded over the ranks (RCCL).
+Run with ``PYTHONPATH=../models python main.py ...`` exactly like the reference.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from tqdm import tqdm
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_MODELS = os.path.join(os.path.dirname(_HERE), "models")
+if _MODELS not in sys.path:
+    sys.path.insert(0, _MODELS)
+
+import patchcore  # noqa: E402
+import patchcore.backbones  # noqa: E402
+import patchcore.common  # noqa: E402
+import patchcore.sampler  # noqa: E402
+import patchcore.datasets.mvtec as mvtec  # noqa: E402
+import patchcore.datasets.synthetic as synthetic  # noqa: E402
+from patchcore.patchcore import AnomalyClusteringCore  # noqa: E402
+from patchcore.pipeline import HipOps, run_category  # noqa: E402
+
+device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu")
+
+_CLASSNAMES = [
+    "bottle", "cable", "capsule", "carpet", "grid", "hazelnut", "leather", "metal_nut", "pill", "screw",
+    "tile", "toothbrush", "transistor", "wood", "zipper",
+]
+
+
+def artefact_dir(save_path, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension, tau, train_ratio):
+    """Path scheme of the reference (main.py:298-301)."""
+    return (save_path + "/" + "_".join(layers_to_extract_from) + "_" + str(pretrain_embed_dimension) + "_" +
+            str(target_embed_dimension) + "_" + str(float(tau)) + "_" + str(float(train_ratio)))
+
+
+def _dataset(path, category, split, dataset):
+    if dataset != "synthetic" and os.path.isdir(os.path.join(path, category)):
+        return mvtec.MVTecDataset(source=path, split=split, classname=category, resize=256, imagesize=224)
+    return synthetic.SyntheticMVTecDataset(source=path, split=synthetic.DatasetSplit(split.value),
+                                           classname=category, resize=256, imagesize=224)
+
+
+def _stack_images(ds):
+    if isinstance(ds, synthetic.SyntheticMVTecDataset):
+        return ds.images
+    return torch.stack([ds[i]["image"] for i in range(len(ds))])
+
+
+def make_category_data(path, category, pretrain_embed_dimension, target_embed_dimension, backbone_names,
+                       layers_to_extract_from, patchsize, save_path, train_ratio=1.0, tau=1, supervised="unsupervised",
+                       dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=32):
+    print("{:-^80}".format(category + ' start ' + supervised))
+    faiss_on_gpu = True
+    faiss_num_workers = 4
+    input_shape = (3, 224, 224)
+    anomaly_scorer_num_nn = 5
+    sampler = patchcore.sampler.IdentitySampler()
+    backbone_seed = None
+    backbone_name = backbone_names[0]
+
+    test_dataset = _dataset(path, category, mvtec.DatasetSplit.TEST, dataset)
+    test_dataloader = torch.utils.data.DataLoader(test_dataset, batch_size=1, shuffle=False, num_workers=0)
+
+    if len(backbone_names) > 1:
+        coll = [[] for _ in range(len(backbone_names))]
+        for layer in layers_to_extract_from:
+            idx = int(layer.split(".")[0])
+            coll[idx].append(".".join(layer.split(".")[1:]))
+    else:
+        coll = [layers_to_extract_from]
+    layers_to_extract_from = coll[0]
+
+    if ".seed-" in backbone_name:
+        backbone_name, backbone_seed = backbone_name.split(".seed-")[0], int(backbone_name.split("-")[-1])
+    if backbone is None:
+        backbone = patchcore.backbones.load(backbone_name)
+    backbone.name, backbone.seed = backbone_name, backbone_seed
+
+    nn_method = patchcore.common.FaissNN(faiss_on_gpu, faiss_num_workers)
+    core = AnomalyClusteringCore(device)
+    core.load(backbone=backbone, layers_to_extract_from=layers_to_extract_from, device=device,
+              input_shape=input_shape, pretrain_embed_dimension=pretrain_embed_dimension,
+              target_embed_dimension=target_embed_dimension, patchsize=patchsize, featuresampler=sampler,
+              anomaly_scorer_num_nn=anomaly_scorer_num_nn, nn_method=nn_method)
+
+    # per-image records (collated with batch size 1, minus pixels) - what test.py reads as `info`
+    info = []
+    with tqdm(total=len(test_dataloader)) as progress:
+        for item in test_dataloader:
+            if isinstance(item, dict):
+                del item['image']
+                del item['mask']
+                info.append(item)
+            progress.update(1)
+
+    images = _stack_images(test_dataset)
+    train_images = None
+    if supervised == "supervised":
+        train_images = _stack_images(_dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset))
+    out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
+                       train_images=train_images, train_ratio=train_ratio, want_pdist=False)
+    matrix_alpha, X = out["alpha"], out["X"]
+
+    data_matrix = (matrix_alpha.cpu(), X)
+    rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    if rank0:
+        folder = artefact_dir(save_path, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension,
+                              tau, train_ratio)
+        os.makedirs(folder, exist_ok=True)
+        torch.save(data_matrix, folder + "/matrix_alpha_X_" + category + "_" + supervised + ".pickle")
+        if info_dir is not None:
+            os.makedirs(info_dir, exist_ok=True)
+            torch.save(info, os.path.join(info_dir, "info_" + category + ".pickle"))
+    print("{:-^80}".format(category + ' end'))
+    return data_matrix
+
+
+def build_parser():
+    parser = argparse.ArgumentParser('Calculating Matrix on MVTec AD')
+    parser.add_argument('--path', default='data/mvtec_ad', type=str, help="Path to the dataset.")
+    parser.add_argument('--backbone_names', nargs='+', default=["dino_vitbase8"], help='Architecture.')
+    parser.add_argument('--layers_to_extract_from', nargs='+', default=["blocks.10", "blocks.11"])
+    parser.add_argument('--pretrain_embed_dimension', default=2048, type=int, help='Pretrained Embedding Dimension')
+    parser.add_argument('--target_embed_dimension', default=4096, type=int, help='Target Embedding Dimension')
+    parser.add_argument('--output_dir', default="outputs", help='Path where to save segmentations')
+    parser.add_argument("--patchsize", type=int, default=3, help="Patch Size.")
+    parser.add_argument("--tau", type=float, default=1, help="Tau.")
+    parser.add_argument("--train_ratio", type=float, default=1, help="The ratio of train data.")
+    parser.add_argument('--supervised', default='unsupervised', type=str,
+                        help="unsupervised | supervised | average | both")
+    parser.add_argument('--dataset', default='mvtec_ad', type=str, help="Dataset to use (mvtec_ad | synthetic).")
+    parser.add_argument('--categories', nargs='*', default=None, help="Subset of categories (default: all 15).")
+    parser.add_argument('--batch_size', type=int, default=32, help="Images per ViT launch.")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=device)
+    modes = ["unsupervised", "supervised"] if args.supervised == "both" else [args.supervised]
+    backbone = patchcore.backbones.load(args.backbone_names[0].split(".seed-")[0])   # once, not once per category
+    results = {}
+    for supervised in modes:
+        save_path = args.output_dir + "/" + args.dataset + "/" + args.backbone_names[0] + "/" + supervised
+        os.makedirs(save_path, exist_ok=True)
+        for category in (args.categories or _CLASSNAMES):
+            results[(supervised, category)] = make_category_data(
+                path=args.path, category=category, pretrain_embed_dimension=args.pretrain_embed_dimension,
+                target_embed_dimension=args.target_embed_dimension, backbone_names=args.backbone_names,
+                layers_to_extract_from=args.layers_to_extract_from, patchsize=args.patchsize, save_path=save_path,
+                tau=args.tau, train_ratio=args.train_ratio, supervised=supervised, dataset=args.dataset,
+                info_dir=args.output_dir + "/" + args.dataset + "/info", backbone=backbone,
+                batch_size=args.batch_size)
+    return results
+
+
+if __name__ == "__main__":
+    main()

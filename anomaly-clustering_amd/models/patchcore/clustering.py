@@ -57,12 +57,14 @@ def agglomerative_ward(X, n_clusters, device=None):
     X: float32 array / tensor [N, D]."""
     if not isinstance(X, torch.Tensor):
         X = torch.from_numpy(np.ascontiguousarray(np.asarray(X, dtype=np.float32)))
-    if device is None:
-        device = X.device if X.is_cuda else torch.device("cuda:0")
+    if device is None and not X.is_cuda and torch.cuda.is_available():
+        device = torch.device("cuda:0")
+    if device is not None:
+        X = X.to(device)
     n = X.shape[0]
     if n == 1:
         return np.zeros(1, dtype=np.intp)
-    condensed = acnative.pdist(X.to(device=device, dtype=torch.float32).contiguous())
+    condensed = acnative.pdist(X.to(torch.float32).contiguous())    # raises on a CPU tensor: no CPU fallback
     children = ward_children(condensed.cpu().numpy(), n)
     return cut_tree(children, n_clusters, n)
 

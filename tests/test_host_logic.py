@@ -1,0 +1,188 @@
+"""CPU: host-side logic of the drop-in (tree cut, label matching, sharding, path / CSV / pickle
+formats, datasets).  Where a function needs the GPU pdist, the test swaps `acnative.pdist` for the
+oracle's (tests are the only place that is allowed)."""
+import csv
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import EXAMPLES
+
+
+@pytest.fixture()
+def oracle_pdist(monkeypatch):
+    import acnative
+    from oracle import cluster as oc
+    monkeypatch.setattr(acnative, "pdist", lambda X: torch.from_numpy(oc.pdist(X.cpu().numpy())))
+
+
+def _examples():
+    if EXAMPLES not in sys.path:
+        sys.path.insert(0, EXAMPLES)
+    sys.modules.pop("test", None)
+    import importlib
+    main = importlib.import_module("main")
+    spec = importlib.util.spec_from_file_location("ac_examples_test", os.path.join(EXAMPLES, "test.py"))
+    test_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(test_mod)
+    return main, test_mod
+
+
+def test_cut_tree_equals_sklearn_cut():
+    from sklearn.cluster._agglomerative import _hc_cut
+    from scipy.cluster import hierarchy
+    from patchcore.clustering import cut_tree, ward_children
+    from oracle.cluster import pdist
+    rng = np.random.default_rng(3)
+    for n, k in [(2, 1), (2, 2), (7, 3), (40, 6), (41, 41)]:
+        X = rng.normal(size=(n, 5))
+        children = ward_children(pdist(X), n)
+        ref_children = hierarchy.ward(X)[:, :2].astype(np.intp)
+        assert np.array_equal(children, ref_children)
+        assert np.array_equal(cut_tree(children, k, n), _hc_cut(k, ref_children, n))
+    with pytest.raises(ValueError):
+        cut_tree(children, n + 1, n)
+
+
+@pytest.mark.parametrize("name", ["kat_toothbrush_unsupervised", "kat_grid_unsupervised", "kat_toothbrush_supervised"])
+def test_cluster_metrics_known_answer_rows(golden, oracle_pdist, name):
+    """Product host logic (own cut / relabel / scipy linkage on a condensed matrix) on the reference's
+    committed X reproduces the reference's CSV rows."""
+    from patchcore.clustering import cluster_metrics
+    g = golden(name + ".npz")
+    NMI, ARI, F1, label, predict = cluster_metrics(g["X"], list(g["anomaly"]), device=torch.device("cpu"))
+    np.testing.assert_allclose([NMI, ARI, F1], g["expected"], rtol=0, atol=1e-12)
+
+
+def test_best_map_matches_oracle():
+    from patchcore.clustering import best_map
+    from oracle.cluster import best_map as ref
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        k = int(rng.integers(2, 7))
+        L1, L2 = rng.integers(0, k, 60), rng.integers(0, k, 60) + 10
+        assert np.array_equal(best_map(L1, L2), ref(L1, L2))
+
+
+def test_shard_bounds_and_bank():
+    from patchcore.pipeline import shard_bounds, select_bank
+    assert shard_bounds(83, 8) == [(0, 11), (11, 22), (22, 33), (33, 44), (44, 55), (55, 66), (66, 77), (77, 83)]
+    assert shard_bounds(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert shard_bounds(10, 1) == [(0, 10)]
+    for n, w in [(1725, 8), (167, 8), (42, 5), (0, 2)]:
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+    a, b = select_bank(209, 83, 1.0, seed=0), select_bank(209, 83, 1.0, seed=0)
+    assert torch.equal(a, b) and len(a) == 83 and len(set(a.tolist())) == 83       # N_test, not N_train (main.py:281)
+    assert len(select_bank(60, 42, 2.0)) == 60 and len(select_bank(60, 42, 0.5)) == 21
+
+
+def test_artefact_paths_match_reference_scheme():
+    main, test_mod = _examples()
+    d = main.artefact_dir("outputs/mvtec_ad/dino_vitbase8/unsupervised", ["blocks.10", "blocks.11"], 2048, 4096, 2, 1)
+    assert d == "outputs/mvtec_ad/dino_vitbase8/unsupervised/blocks.10_blocks.11_2048_4096_2.0_1.0"
+    p = test_mod.artefact_path("bottle", 2048, 4096, ["dino_vitbase8"], ["blocks.10", "blocks.11"], 1, 2,
+                               "unsupervised", "mvtec_ad")
+    assert p == ("../outputs/mvtec_ad/dino_vitbase8/unsupervised/blocks.10_blocks.11_2048_4096_2.0_1.0/"
+                 "matrix_alpha_X_bottle_unsupervised.pickle")
+    args = main.build_parser().parse_args([])
+    assert (args.path, args.backbone_names, args.layers_to_extract_from, args.pretrain_embed_dimension,
+            args.target_embed_dimension, args.output_dir, args.patchsize, args.tau, args.train_ratio,
+            args.supervised, args.dataset) == ("data/mvtec_ad", ["dino_vitbase8"], ["blocks.10", "blocks.11"], 2048,
+                                               4096, "outputs", 3, 1, 1, "unsupervised", "mvtec_ad")
+
+
+def test_sweep_csv_layout_and_pickle_round_trip(tmp_path, oracle_pdist, golden):
+    """Write artefacts in main.py's format from the reference's committed X, then run test.py's sweep."""
+    main, test_mod = _examples()
+    out = str(tmp_path / "outputs")
+    g = {"toothbrush": golden("kat_toothbrush_unsupervised.npz"), "grid": golden("kat_grid_unsupervised.npz")}
+    layers = ["blocks.10", "blocks.11"]
+    for cat, gg in g.items():
+        folder = main.artefact_dir(out + "/mvtec_ad/dino_vitbase8/unsupervised", layers, 2048, 4096, 2, 1)
+        os.makedirs(folder, exist_ok=True)
+        n = len(gg["anomaly"])
+        torch.save((torch.full((n, 1, 784), 1.0 / 784), gg["X"]),
+                   folder + "/matrix_alpha_X_%s_unsupervised.pickle" % cat)
+        os.makedirs(out + "/mvtec_ad/info", exist_ok=True)
+        info = [{"classname": [cat], "anomaly": [str(a)], "is_anomaly": torch.tensor([int(a != "good")]),
+                 "image_name": ["x"], "image_path": ["y"]} for a in gg["anomaly"]]
+        torch.save(info, out + "/mvtec_ad/info/info_%s.pickle" % cat)
+    files = test_mod.sweep(["unsupervised"], [2], 2048, 4096, ["dino_vitbase8"], layers, 3, 1, output_dir=out,
+                           objects=["toothbrush"], textures=["grid"])
+    assert files[0].endswith("blocks.10_blocks.11_2048_4096_tau_result.csv")
+    rows = list(csv.reader(open(files[0], encoding="gbk")))
+    assert rows[0] == ["unsupervised"] and rows[1] == ["Category", "NMI", "ARI", "F1"]
+    assert rows[2] == ["---"] * 4 and rows[3] == ["TAU=2"]
+    assert [r[0] for r in rows[4:]] == ["toothbrush", "grid", "MVTec(object)", "MVTec(texture)"]
+    np.testing.assert_allclose([float(v) for v in rows[4][1:]], g["toothbrush"]["expected"], atol=1e-12)
+    np.testing.assert_allclose([float(v) for v in rows[5][1:]], g["grid"]["expected"], atol=1e-12)
+    np.testing.assert_allclose([float(v) for v in rows[6][1:]], g["toothbrush"]["expected"], atol=1e-12)
+
+
+def test_synthetic_dataset_shapes_and_histograms():
+    from patchcore.datasets import synthetic
+    sizes = {c: sum(n for _, n in h) for c, h in synthetic.TEST_HISTOGRAMS.items()}
+    assert list(sizes.values()) == [83, 150, 132, 117, 78, 110, 124, 115, 167, 160, 117, 42, 100, 79, 151]
+    assert sum(sizes.values()) == 1725 and sum(synthetic.TRAIN_SIZES.values()) == 3629
+    ds = synthetic.SyntheticMVTecDataset(classname="toothbrush", split=synthetic.DatasetSplit.TEST)
+    assert len(ds) == 42
+    item = ds[0]
+    assert set(item) == {"image", "mask", "classname", "anomaly", "is_anomaly", "image_name", "image_path"}
+    assert item["image"].shape == (3, 224, 224) and item["mask"].shape == (1, 224, 224)
+    assert item["anomaly"] == "defective" and item["is_anomaly"] == 1 and ds[41]["anomaly"] == "good"
+    again = synthetic.SyntheticMVTecDataset(classname="toothbrush", split=synthetic.DatasetSplit.TEST)
+    assert torch.equal(ds.images, again.images)
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=1)))
+    assert batch["anomaly"] == ["defective"] and batch["is_anomaly"].tolist() == [1]
+
+
+def test_mvtec_folder_dataset(tmp_path):
+    import PIL.Image
+    from patchcore.datasets import mvtec
+    root = tmp_path / "mv"
+    rng = np.random.default_rng(0)
+    for split, kinds in (("train", ["good"]), ("test", ["good", "crack"])):
+        for kind in kinds:
+            os.makedirs(root / "nut" / split / kind)
+            for i in range(2):
+                PIL.Image.fromarray(rng.integers(0, 255, (300, 320, 3), dtype=np.uint8)).save(
+                    root / "nut" / split / kind / ("%03d.png" % i))
+    os.makedirs(root / "nut" / "ground_truth" / "crack")
+    for i in range(2):
+        PIL.Image.fromarray(rng.integers(0, 2, (300, 320), dtype=np.uint8) * 255).save(
+            root / "nut" / "ground_truth" / "crack" / ("%03d_mask.png" % i))
+    ds = mvtec.MVTecDataset(str(root), "nut", split=mvtec.DatasetSplit.TEST)
+    assert len(ds) == 4 and [ds.data_to_iterate[i][1] for i in range(4)] == ["crack", "crack", "good", "good"]
+    item = ds[0]
+    assert item["image"].shape == (3, 224, 224) and item["mask"].shape == (1, 224, 224)
+    assert item["image_name"] == "nut/test/crack/000.png" and item["is_anomaly"] == 1
+    assert abs(float(item["image"].mean())) < 1.0 and float(item["mask"].max()) <= 1.0
+    assert float(ds[2]["mask"].abs().sum()) == 0.0
+    with pytest.raises(FileNotFoundError):
+        mvtec.MVTecDataset(str(tmp_path / "missing"), "nut")
+
+
+def test_backbone_registry():
+    import patchcore.backbones as bb
+    with pytest.raises(NotImplementedError):
+        bb.load("wideresnet50")
+    assert set(bb._DINO) == {"dino_deitsmall16", "dino_deitsmall8_300ep", "dino_vitbase16", "dino_vitbase8"}
+
+
+def test_shims_construct_and_refuse_detection_calls():
+    import patchcore.common as common
+    import patchcore.sampler
+    nn = common.FaissNN(True, 4)
+    scorer = common.NearestNeighbourScorer(n_nearest_neighbours=5, nn_method=nn)
+    seg = common.RescaleSegmentor(device="cpu", target_size=(224, 224))
+    assert scorer.nn_method is nn and seg.smoothing == 4
+    assert patchcore.sampler.IdentitySampler().run(3) == 3
+    with pytest.raises(NotImplementedError):
+        scorer.fit([])
+    pre = common.Preprocessing([785, 785], 2048)
+    assert pre.output_dim == 2048 and len(pre.preprocessing_modules) == 2
+    assert common.Aggregator(target_dim=4096).target_dim == 4096
