@@ -95,7 +95,51 @@ struct EpiPairMin {
       }
     }
   }
+
+  // Symmetric case (keys == queries, M == N): the same tile read the other way - the block's ROWS
+  // are the query patches, its COLUMNS the key patches.  The wave's 64x32 slab of d2 goes through
+  // LDS transposed ([column][row], 65-float pitch), then lane l owns row l and takes the min over
+  // the columns of each key image.
+  __device__ void transposed(const gemm::Frag& f, int m_wave, int n_wave, int lane, float* tb) const {
+    const int r = lane & 31, h = lane >> 5;
+    if (m_wave >= M || n_wave >= N) return;       // wave-uniform
+    float ksq[2][16];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        ksq[mi][i] = key_sq[min(row, M - 1)];
+      }
+    const int my_row = m_wave + lane;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int c_base = n_wave + ni * 32;
+      if (c_base >= N) break;                      // wave-uniform
+      const int col = c_base + r;
+      const float qs = qry_sq[min(col, N - 1)];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          tb[r * 65 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] =
+              fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int c_end = min(c_base + 32, N);
+      for (int img = c_base / P; img <= (c_end - 1) / P; ++img) {   // wave-uniform, <= 2 trips when P >= 32
+        const int lo = max(img * P, c_base) - c_base, hi = min((img + 1) * P, c_end) - c_base;
+        float mn = __builtin_inff();
+        for (int c = lo; c < hi; ++c) mn = fminf(mn, tb[c * 65 + lane]);
+        if (my_row < M) atomicMin(minbuf + (size_t)img * N + my_row, __float_as_uint(mn));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  bool symmetric;
 };
+template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; };
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,7 +218,7 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
     size_t cells = (size_t)nk * N;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096)),
                        dim3(256), 0, stream, minbuf, cells, 0x7f800000u);
-    EpiPairMin epi{sk, sq + q0 * P, minbuf, M, N, P};
+    EpiPairMin epi{sk, sq + q0 * P, minbuf, M, N, P, same && chunk == nq};   // whole square in one launch -> C = C^T
     rc = gemm::launch(hk, hq + (size_t)q0 * P * D * 4, M, N, D, epi, stream, 16);
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, minbuf, nk,
@@ -190,7 +234,7 @@ extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64
   AC_REQUIRE(Zk_hl && k_sq && Zq_hl && q_sq && minbuf, "ac_pair_min_sq_packed: null pointer");
   AC_REQUIRE(nq > 0 && nk > 0 && P > 0 && D > 0 && D % 32 == 0, "ac_pair_min_sq_packed: bad shape");
   AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_sq_packed: too many patches");
-  EpiPairMin epi{k_sq, q_sq, minbuf, (int)(nk * P), (int)(nq * P), P};
+  EpiPairMin epi{k_sq, q_sq, minbuf, (int)(nk * P), (int)(nq * P), P, Zk_hl == Zq_hl && nk == nq};
   return gemm::launch(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), 16);
 }
 

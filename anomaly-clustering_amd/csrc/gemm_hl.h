@@ -48,6 +48,12 @@ struct Frag {   // register image of one wave's 64x64 accumulator
   f32x16 acc[2][2];
 };
 
+// Epilogues that can exploit C = C^T (A and B are the same matrix) specialise this to true and
+// provide `bool symmetric` plus `transposed(frag, m_wave, n_wave, lane, float* lds_scratch)`:
+// only tiles with tile_m <= tile_n are computed, and every off-diagonal tile is reduced in both
+// directions (the scratch is this wave's 32x65-float slice of the then-idle staging LDS).
+template <class Epi> struct EpiTraits { static constexpr bool kSymmetric = false; };
+
 // Epi must provide:  __device__ void operator()(const Frag&, int m_wave, int n_wave, int lane) const
 //   m_wave / n_wave = first row / column of this wave's 64x64 sub-tile.
 // Element (mi, ni, i) of lane l sits at row m_wave + mi*32 + (i&3) + 8*(i>>2) + 4*(l>>5),
@@ -63,6 +69,19 @@ __global__ __launch_bounds__(256, 2) void gemm_hl_kernel(const uint8_t* __restri
 
   int tm, tn;
   raster(blockIdx.x, tiles_m, tiles_n, group_m, tm, tn);
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {
+      // The grid is the upper triangle (tm <= tn) of a T x T tile matrix, folded into a
+      // ceil(T/2) x (T+1) rectangle so every XCD gets the same amount of work: folded row p holds
+      // row p (T-p tiles) followed by row T-1-p (p+1 tiles).
+      const int T = tiles_n - 1, p = tm, c = tn;
+      if (c < T - p) { tm = p; tn = p + c; }
+      else {
+        if (2 * p == T - 1) return;                // odd T: the middle row is paired with itself
+        tm = T - 1 - p; tn = tm + (c - (T - p));
+      }
+    }
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- global -> register staging map: 8 threads cover one 128-byte row group
@@ -171,6 +190,10 @@ __global__ __launch_bounds__(256, 2) void gemm_hl_kernel(const uint8_t* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) tot.acc[mi][ni][i] += f.acc[mi][ni][i];
   epi(tot, m0 + wm * 64, n0 + wn * 64, lane);
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric && tm != tn)                 // all waves are past the loop's last barrier: LDS is free
+      epi.transposed(tot, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65));
+  }
 }
 
 // Host launcher.  M, N arbitrary (tails are clamped on load; the epilogue masks them), K % 32 == 0.
@@ -180,6 +203,14 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl: K=%d must be a positive multiple of 32", K);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {                           // folded upper triangle (see the kernel)
+      if (M != N) return ac_fail(AC_EINVAL, "gemm_hl: symmetric epilogue needs M == N");
+      const int T = tiles_m;
+      tiles_m = (T + 1) / 2;
+      tiles_n = T + 1;
+    }
+  }
   long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl: grid too large");
   static bool attr_set = false;   // per instantiation

@@ -118,15 +118,23 @@ def test_full_size_against_reference_golden(golden, dev):
 
 
 def test_query_shard_matches_whole(dev):
-    """Sharded queries with self_offset (the multi-GPU call shape) == the unsharded call, bit for bit."""
+    """Sharded queries with self_offset (the multi-GPU call shape) vs the unsharded call.  The unsharded
+    call takes the symmetric path (only tiles tm <= tn, each reduced in both directions); the sharded /
+    cloned-key calls take the general path: same values up to the order of two fp32 additions."""
     import acnative
     Zs, _ = clustered_embeddings(7, 100, 256, 3, salt=51)
     Z = torch.from_numpy(Zs).to(dev)
     whole = acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS)
+    general = acnative.pair_min_dist(Z, Z.clone(), acnative.REDUCE_MEAN_OTHERS)
+    staged = acnative.pair_min_dist_staged(Z, Z, acnative.REDUCE_MEAN_OTHERS)
     part = acnative.pair_min_dist(Z[3:6].contiguous(), Z, acnative.REDUCE_MEAN_OTHERS, self_offset=3)
-    assert torch.equal(whole[3:6], part)
+    part_staged = acnative.pair_min_dist_staged(Z[3:6], Z, acnative.REDUCE_MEAN_OTHERS, self_offset=3)
+    assert torch.equal(general[3:6], part) and torch.equal(part, part_staged)      # general path: bit for bit
+    assert torch.equal(whole, staged)                                               # symmetric path: bit for bit
+    np.testing.assert_allclose(whole.cpu().numpy(), general.cpu().numpy(), rtol=1e-6, atol=1e-6)
     ref = _truth_w(Zs, Zs, 0)
     assert np.abs(whole.cpu().numpy() - ref).max() <= 2e-5
+    assert np.abs(general.cpu().numpy() - ref).max() <= 2e-5
 
 
 def test_ragged_edges_vs_oracle(dev):
