@@ -2,7 +2,8 @@
 // fp64 softmax, weighted-average embedding, condensed pdist.
 // Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
 // scipy pdist under examples/test.py:193-195.
-#include "gemm_hl.h"
+#include "gemm_hl2.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ packing
 // fp32 [rows, K] -> hl32 + optional squared row norms.  One wave per row; each lane
@@ -139,7 +140,15 @@ struct EpiPairMin {
   }
   bool symmetric;
 };
-template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; };
+template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; static constexpr bool kStaged = false; };
+
+// general (non-symmetric) launches use the LDS-DMA ring kernel unless AC_GEMM=1
+static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 2; }
+  if (epi.symmetric || v == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
+  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, 8);
+}
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -219,7 +228,7 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096)),
                        dim3(256), 0, stream, minbuf, cells, 0x7f800000u);
     EpiPairMin epi{sk, sq + q0 * P, minbuf, M, N, P, same && chunk == nq};   // whole square in one launch -> C = C^T
-    rc = gemm::launch(hk, hq + (size_t)q0 * P * D * 4, M, N, D, epi, stream, 16);
+    rc = launch_pair_min(hk, hq + (size_t)q0 * P * D * 4, M, N, D, epi, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, minbuf, nk,
                        (int64_t)N, P, reduce, self_offset + q0, w + q0 * P);
@@ -235,7 +244,7 @@ extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64
   AC_REQUIRE(nq > 0 && nk > 0 && P > 0 && D > 0 && D % 32 == 0, "ac_pair_min_sq_packed: bad shape");
   AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_sq_packed: too many patches");
   EpiPairMin epi{k_sq, q_sq, minbuf, (int)(nk * P), (int)(nq * P), P, Zk_hl == Zq_hl && nk == nq};
-  return gemm::launch(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), 16);
+  return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream));
 }
 
 extern "C" int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,

@@ -52,7 +52,11 @@ struct Frag {   // register image of one wave's 64x64 accumulator
 // provide `bool symmetric` plus `transposed(frag, m_wave, n_wave, lane, float* lds_scratch)`:
 // only tiles with tile_m <= tile_n are computed, and every off-diagonal tile is reduced in both
 // directions (the scratch is this wave's 32x65-float slice of the then-idle staging LDS).
-template <class Epi> struct EpiTraits { static constexpr bool kSymmetric = false; };
+// kStaged: the epilogue also provides `staged(const float* tile, m_wave, n_wave, lane)`, which reads the
+// wave's 64x64 result back from LDS ([row][EPI_PITCH floats]) one row segment per lane, so that it can
+// emit full 128-byte lines with 16-byte stores (gemm_hl2.h uses it; the 64 KB kernel cannot).
+template <class Epi> struct EpiTraits { static constexpr bool kSymmetric = false; static constexpr bool kStaged = false; };
+constexpr int EPI_PITCH = 68;   // floats per staged row: 16-byte aligned, conflict-free for ds_read_b128
 
 // Epi must provide:  __device__ void operator()(const Frag&, int m_wave, int n_wave, int lane) const
 //   m_wave / n_wave = first row / column of this wave's 64x64 sub-tile.

@@ -8,9 +8,22 @@
 // everything that feeds an MFMA (LN output, q/k/v, attention output, GELU output) is written
 // directly in hl32 form by the producing kernel's epilogue - same bytes as fp32, no
 // conversion pass.
-#include "gemm_hl.h"
+#include "gemm_hl2.h"
+#include <stdlib.h>
 
 constexpr int HD = 64;          // head dim (all DINO ViTs)
+
+// AC_GEMM=1 selects the first-generation 128x128 register-staged kernel (A/B runs); default: LDS-DMA ring.
+static int gemm_version() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 2; }
+  return v;
+}
+template <class Epi>
+static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
+  return gemm_version() == 1 ? gemm::launch(A, B, M, N, K, epi, stream)
+                             : gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream);
+}
 
 __host__ __device__ inline int tpad_of(int T) { return (T + 31) / 32 * 32; }
 
@@ -58,10 +71,10 @@ struct EpiPatchEmbed {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (row < M) {
-            int b = row / PP, p = row - b * PP;
-            x[((size_t)b * T + 1 + p) * N + col] = (f.acc[mi][ni][i] + bc) + pos[(size_t)(1 + p) * N + col];
-          }
+          int rc = min(row, M - 1);
+          int b = rc / PP, p = rc - b * PP;
+          float pv = pos[(size_t)(1 + p) * N + col];          // unconditional load (see EpiResidual)
+          if (row < M) x[((size_t)b * T + 1 + p) * N + col] = (f.acc[mi][ni][i] + bc) + pv;
         }
     }
   }
@@ -118,6 +131,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------ GEMM epilogues
+// helpers of the LDS-staged epilogues: 32 consecutive result columns of one row (+ bias) ...
+__device__ inline void load_staged_row(const float* t, const float* bias32, float* v) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(t + 4 * c);
+    f32x4 b = *reinterpret_cast<const f32x4*>(bias32 + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * c + j] = a[j] + b[j];
+  }
+}
+// ... written as one 128-byte hl32 group: 32 hi halves then 32 lo halves
+__device__ inline void store_hl32_line(uint8_t* line, const float* v) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    half8 hi, lo;
+    split8(v + 8 * c, hi, lo);
+    *reinterpret_cast<half8*>(line + 16 * c) = hi;
+    *reinterpret_cast<half8*>(line + 64 + 16 * c) = lo;
+  }
+}
+
 // q,k: rows = tokens (b*T + t), cols in [0, 2C): dest hl32 [which][B*H][Tpad][64]
 struct EpiQK {
   const float* bias; uint8_t* q; uint8_t* k; int M, C, T, Tpad, H;
@@ -146,7 +180,23 @@ struct EpiQK {
         }
     }
   }
+  // LDS-staged form: a wave's 64 columns are exactly one head of q or k; lane -> (token row, half of
+  // the head), one full 128-byte hl32 group per item
+  __device__ void staged(const float* tl, int m_wave, int n_wave, int lane) const {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int item = pass * 64 + lane, rl = item >> 1, half = item & 1;
+      const int row = m_wave + rl, col0 = n_wave + half * 32;
+      if (row >= M || col0 >= 2 * C) continue;
+      float v[32];
+      load_staged_row(tl + rl * gemm::EPI_PITCH + half * 32, bias + col0, v);
+      const int which = col0 / C, fcol = col0 - which * C, head = fcol >> 6, dh = (fcol & 63) >> 5;
+      const int b = row / T, t = row - b * T;
+      store_hl32_line((which ? k : q) + (((size_t)b * H + head) * Tpad + t) * (HD * 4) + dh * 128, v);
+    }
+  }
 };
+template <> struct gemm::EpiTraits<EpiQK> { static constexpr bool kSymmetric = false; static constexpr bool kStaged = true; };
 
 // v, transposed: rows = v feature (head*64 + d) on the registers, cols = tokens on the lanes:
 // dest hl32 [B*H][64][Tpad] (K axis = token), so consecutive lanes write consecutive halves.
@@ -187,19 +237,42 @@ struct EpiResidual {
       const int col = n_wave + ni * 32 + r;
       if (col >= N) continue;
       const float bc = bias[col];
+      // all 32 residual loads first, unconditionally (row clamped): a load under `if (row < M)`
+      // makes hipcc branch and wait vmcnt(0) per element - 64 serial round trips per wave
+      float rv[2][16];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int row = min(m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, M - 1);
+          rv[mi][i] = res[(size_t)row * N + col];
+        }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (row < M) {
-            size_t o = (size_t)row * N + col;
-            out[o] = res[o] + (f.acc[mi][ni][i] + bc);
-          }
+          if (row < M) out[(size_t)row * N + col] = rv[mi][i] + (f.acc[mi][ni][i] + bc);
         }
     }
   }
 };
+
+// exact-erf GELU (nn.GELU default): 0.5 v (1 + erf(v / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, i.e. fp32 rounding level) - one v_rcp, one v_exp and a degree-5 Horner chain
+// instead of libm's branchy erff, which made the fc1 epilogue cost as much as its K loop.
+__device__ inline float gelu_erf(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float pe = poly * e;                       // = erfc(z): no cancellation on the negative side
+  return 0.5f * v * (v >= 0.f ? 2.0f - pe : pe);
+}
 
 // g = gelu(acc + bias) (exact erf form, nn.GELU default) -> hl32 [M, N]
 struct EpiGeluHl {
@@ -218,7 +291,7 @@ struct EpiGeluHl {
           int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
           if (row < M) {
             float v = f.acc[mi][ni][i] + bc;
-            v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            v = gelu_erf(v);
             _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
             uint8_t* p = out + (size_t)row * N * 4 + (col >> 5) * 128 + (col & 31) * 2;
             *reinterpret_cast<_Float16*>(p) = hi;
@@ -227,7 +300,22 @@ struct EpiGeluHl {
         }
     }
   }
+  // LDS-staged form: lane -> (row, 32-column half); one full hl32 line (8 x 16-byte stores) per item
+  __device__ void staged(const float* t, int m_wave, int n_wave, int lane) const {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int item = pass * 64 + lane, rl = item >> 1, half = item & 1;
+      const int row = m_wave + rl, col0 = n_wave + half * 32;
+      if (row >= M || col0 >= N) continue;
+      float v[32];
+      load_staged_row(t + rl * gemm::EPI_PITCH + half * 32, bias + col0, v);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v[j] = gelu_erf(v[j]);
+      store_hl32_line(out + (size_t)row * N * 4 + (col0 >> 5) * 128, v);
+    }
+  }
 };
+template <> struct gemm::EpiTraits<EpiGeluHl> { static constexpr bool kSymmetric = false; static constexpr bool kStaged = true; };
 
 // ----------------------------------------------------------------- attention
 // softmax(q k^T * scale) v for one (image, head), flash style, split-fp16 MFMA for both products.
@@ -265,6 +353,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m_run = -__builtin_inff(), l_run = 0.f;
+  const float c_log2 = scale * 1.44269504088896340736f;
 
   const uint8_t* Kbase = K + (size_t)bh * Tpad * (HD * 4);
   const uint8_t* Vbase = Vt + (size_t)bh * HD * ((size_t)Tpad * 4);
@@ -296,32 +385,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s_acc, 0, 0, 0);
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s_acc, 0, 0, 0);
     }
-    // online softmax over the key axis (registers + the other lane half)
-    float sv[16];
-    float mloc = -__builtin_inff();
+    // online softmax over the key axis (registers + the other lane half), in the log2 domain:
+    // p = 2^(s*c - m) with c = scale*log2(e) - one FMA and one v_exp_f32 per score.  Only the last
+    // tile has padded keys (block-uniform branch); the O / l rescale is skipped (wave-uniform
+    // branch) whenever no lane's running maximum moved.
+    if (key0 + ATT_KT > T) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      sv[i] = key < T ? s_acc[i] * scale : -__builtin_inff();
-      mloc = fmaxf(mloc, sv[i]);
+      for (int i = 0; i < 16; ++i) {
+        int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        s_acc[i] = key < T ? s_acc[i] : -__builtin_inff();
+      }
     }
+    float mloc = s_acc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, s_acc[i]);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float corr = expf(m_run - m_new);
-    m_run = m_new;
+    const float m_new = fmaxf(m_run, mloc * c_log2);
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
+      const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= corr;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= corr; o[1][i] *= corr; }
+      m_run = m_new;
+    }
     float psum = 0.f;
     half8 ph[2], pl[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float p = expf(sv[i] - m_new);
+      float p = __builtin_amdgcn_exp2f(fmaf(s_acc[i], c_log2, -m_new));
       psum += p;
       _Float16 hi = (_Float16)p;
       ph[i >> 3][i & 7] = hi;
       pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
     }
-    l_run = l_run * corr + psum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= corr; o[1][i] *= corr; }
+    l_run += psum;
     // O^T += V^T P^T ; A fragment element j <-> key 16s + 8(j>>2) + 4h + (j&3)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -423,7 +520,7 @@ extern "C" int ac_vit_prepare_tokens(const float* images, int B, int in_ch, int 
                      img, patch, cols);
   hipLaunchKernelGGL(set_cls_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, cls, pos, B, T, C, x);
   EpiPatchEmbed epi{proj_b, pos, x, B * PP, C, PP, T};
-  return gemm::launch(cols, proj_w, B * PP, C, Kd, epi, stream);
+  return run_gemm(cols, proj_w, B * PP, C, Kd, epi, stream);
 }
 
 extern "C" int ac_layernorm_rows(const float* x, int64_t rows, int C, const float* w, const float* b, float eps,
@@ -460,9 +557,9 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
                      eps, b.h, (float*)nullptr);
   const uint8_t* wqkv = static_cast<const uint8_t*>(w->qkv_w);
   EpiQK eqk{w->qkv_b, b.q, b.k, M, C, T, Tp, heads};
-  if ((rc = gemm::launch(b.h, wqkv, M, 2 * C, C, eqk, stream))) return rc;
+  if ((rc = run_gemm(b.h, wqkv, M, 2 * C, C, eqk, stream))) return rc;
   EpiVt evt{w->qkv_b + 2 * C, b.vt, C, M, T, Tp, heads};
-  if ((rc = gemm::launch(wqkv + (size_t)2 * C * C * 4, b.h, C, M, C, evt, stream))) return rc;
+  if ((rc = run_gemm(wqkv + (size_t)2 * C * C * 4, b.h, C, M, C, evt, stream))) return rc;
   if (Tp > T) {
     int n = B * heads * HD * (Tp - T);
     hipLaunchKernelGGL(zero_vt_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b.vt, B * heads * HD, T, Tp);
@@ -470,14 +567,14 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
   hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.vt,
                      b.o, T, Tp, heads, 1.0f / sqrtf((float)HD));
   EpiResidual ep{w->proj_b, x_in, x_out, M, C};
-  if ((rc = gemm::launch(b.o, w->proj_w, M, C, C, ep, stream))) return rc;
+  if ((rc = run_gemm(b.o, w->proj_w, M, C, C, ep, stream))) return rc;
 
   // x_out = x_mid + fc2(gelu(fc1(ln2(x_mid))))
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3(ln_grid), dim3(256), 0, stream, x_out, (int64_t)M, C, w->ln2_w,
                      w->ln2_b, eps, b.h, (float*)nullptr);
   EpiGeluHl eg{w->fc1_b, b.g, M, hidden};
-  if ((rc = gemm::launch(b.h, w->fc1_w, M, hidden, C, eg, stream))) return rc;
+  if ((rc = run_gemm(b.h, w->fc1_w, M, hidden, C, eg, stream))) return rc;
   EpiResidual e2{w->fc2_b, x_out, x_out, M, C};
-  if ((rc = gemm::launch(b.g, w->fc2_w, M, C, hidden, e2, stream))) return rc;
+  if ((rc = run_gemm(b.g, w->fc2_w, M, C, hidden, e2, stream))) return rc;
   return ac_check_launch("ac_vit_block");
 }

@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--category", default="bottle", help="MVTec-AD category whose test-set shape is used")
-    ap.add_argument("--batch", type=int, default=32, help="images per ViT launch")
+    ap.add_argument("--batch", type=int, default=128, help="images per ViT launch")
     ap.add_argument("--mode", default="unsupervised", choices=["unsupervised", "supervised", "average"])
     ap.add_argument("--tau", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -69,14 +69,15 @@ def block(sd, i, x, num_heads, eps=1e-6):
 
 
 @torch.no_grad()
-def forward_taps(sd, images, taps=(10, 11), num_heads=12):
-    """Run the ViT and return {block_index: [B, T, C] fp32} for each tap.
+def forward_taps(sd, images, taps=(10, 11), num_heads=12, dtype=torch.float32):
+    """Run the ViT and return {block_index: [B, T, C]} for each tap (fp32 = the reference's
+    arithmetic; dtype=torch.float64 gives the "truth" that stress tests compare both sides to).
 
     Equivalent to NetworkFeatureAggregator.forward (common.py:259-268) with
     layers_to_extract_from = ["blocks.<i>" for i in taps].
     """
-    sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
-    x = prepare_tokens(sd, images.to(torch.float32).cpu())
+    sd = {k: v.detach().to(dtype).cpu() for k, v in sd.items()}
+    x = prepare_tokens(sd, images.to(dtype).cpu())
     out = {}
     last = max(taps)
     for i in range(last + 1):

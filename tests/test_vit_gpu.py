@@ -92,10 +92,13 @@ def test_attention_extreme_logits(dev):
     got = _run(model, images.to(dev), (0,))[0].cpu()
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     ref = ovit.forward_taps(sd, images, taps=(0,))[0]
-    err = (got - ref).abs()
-    print("extreme logits: max err %.3e, |ref| max %.2f" % (err.max().item(), ref.abs().max().item()))
+    truth = ovit.forward_taps(sd, images, taps=(0,), dtype=torch.float64)[0]
+    e_ours, e_ref = (got.double() - truth).abs().max().item(), (ref.double() - truth).abs().max().item()
+    print("extreme logits: |ours-truth| %.3e  |fp32 oracle-truth| %.3e  (|x| max %.1f)" % (e_ours, e_ref, truth.abs().max().item()))
     assert torch.isfinite(got).all()
-    assert torch.all(err <= 5e-3 + 1e-3 * ref.abs())
+    # with logits in the hundreds the softmax is a near-argmax and fp32 itself is ~1e-3 from the truth;
+    # the kernel must stay within a small multiple of the fp32 reference's own distance
+    assert e_ours <= max(4.0 * e_ref, 2e-3)
 
 
 def test_cpu_tensor_is_refused():
