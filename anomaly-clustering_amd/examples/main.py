@@ -62,7 +62,7 @@ def _dataset(path, category, split, dataset):
 
 
 def _stack_images(ds):
-    if isinstance(ds, synthetic.SyntheticMVTecDataset):
+    if hasattr(ds, "images"):            # synthetic dataset: already one tensor
         return ds.images
     return torch.stack([ds[i]["image"] for i in range(len(ds))])
 

@@ -77,7 +77,7 @@ def weighted_average(matrix_alpha, Z):
     """examples/main.py:294-296: alpha -> [N,1,P] float32, X = bmm(alpha, Z) as
     np.float32 [N, D].  Returns (alpha [N,1,P] fp32, X)."""
     a = matrix_alpha.unsqueeze(1).float()
-    X = np.array(torch.bmm(a, Z).squeeze(1).cpu())
+    X = torch.bmm(a, Z).squeeze(1).cpu().numpy().copy()
     return a, X
 
 

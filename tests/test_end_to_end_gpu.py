@@ -1,0 +1,108 @@
+"""GPU: the drop-in scripts end to end (examples/main.py -> pickle -> examples/test.py) on a small
+MVTec-shaped synthetic category, against the oracle run on the same images and weights:
+alpha (tolerance 2e-3 relative: alpha amplifies the fp32-level differences of the 12-block ViT by
+1/tau), X (<= 5e-4 absolute) and NMI / ARI / F1 within +-1e-3 (north_star's bar)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import EXAMPLES
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_examples():
+    import importlib.util
+    mods = []
+    for name in ("main", "test"):
+        spec = importlib.util.spec_from_file_location("ac_examples_" + name, os.path.join(EXAMPLES, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mods.append(mod)
+    return mods
+
+
+@pytest.fixture(scope="module")
+def small_model(dev):
+    """dino_vitbase8 geometry with 4 blocks (taps on the last two) to keep the CPU oracle fast."""
+    import patchcore.vision_transformer as vits
+    torch.manual_seed(0)
+    m = vits.vit_base(patch_size=8, num_classes=0, depth=4)
+    for p in m.parameters():
+        p.requires_grad = False
+    return m.eval().to(dev)
+
+
+def _oracle_category(model, images, mode, tau, train_images=None, bank_idx=None):
+    from oracle import vit as ovit, aggregate as oagg, alpha as oalpha
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+
+    def embed(x):
+        out = []
+        for i in range(0, x.shape[0], 4):
+            taps = ovit.forward_taps(sd, x[i:i + 4], taps=(2, 3))
+            out.append(oagg.aggregate([taps[2], taps[3]], 3, 2048, 4096)[0].reshape(-1, 784, 4096))
+        return torch.cat(out)
+
+    Z = embed(images)
+    if mode == "unsupervised":
+        a64 = oalpha.matrix_alpha_unsupervised(tau, 1, Z)
+    elif mode == "supervised":
+        a64 = oalpha.matrix_alpha_supervised(tau, 1, Z, embed(train_images[bank_idx]))
+    else:
+        a64 = oalpha.matrix_alpha_average(Z)
+    return oalpha.weighted_average(a64, Z)
+
+
+@pytest.mark.parametrize("mode", ["unsupervised", "supervised", "average"])
+def test_main_then_test_scripts_match_oracle(tmp_path, dev, small_model, mode, monkeypatch):
+    main, test_mod = _load_examples()
+    from patchcore.datasets import synthetic
+    from patchcore.pipeline import select_bank
+    from oracle import cluster as ocluster
+
+    limit = 3                                                 # 3 images per anomaly type of "grid": N = 18, 6 classes
+    orig = synthetic.SyntheticMVTecDataset
+
+    def small(**kw):
+        kw["limit_per_class"] = limit if kw.get("split") == synthetic.DatasetSplit.TEST else None
+        ds = orig(**kw)
+        if kw.get("split") != synthetic.DatasetSplit.TEST:     # shrink the train split too
+            ds.anomalies, ds.images = ds.anomalies[:24], ds.images[:24]
+        return ds
+    monkeypatch.setattr(synthetic, "SyntheticMVTecDataset", small)
+
+    out = str(tmp_path / "outputs")
+    layers = ["blocks.2", "blocks.3"]
+    save_path = out + "/mvtec_ad/dino_vitbase8/" + mode
+    alpha, X = main.make_category_data(
+        path="nowhere", category="grid", pretrain_embed_dimension=2048, target_embed_dimension=4096,
+        backbone_names=["dino_vitbase8"], layers_to_extract_from=layers, patchsize=3, save_path=save_path,
+        tau=1, train_ratio=1.0, supervised=mode, dataset="mvtec_ad", info_dir=out + "/mvtec_ad/info",
+        backbone=small_model, batch_size=8)
+    n = X.shape[0]
+    assert alpha.shape == (n, 1, 784) and alpha.dtype == torch.float32 and X.dtype == np.float32 and X.shape == (n, 4096)
+
+    # the same inputs through the oracle
+    test_ds = small(classname="grid", split=synthetic.DatasetSplit.TEST)
+    train_ds = small(classname="grid", split=synthetic.DatasetSplit.TRAIN)
+    bank = select_bank(len(train_ds), n, 1.0, 0)
+    a_ref, X_ref = _oracle_category(small_model, test_ds.images, mode, 1.0, train_ds.images, bank)
+    a = alpha.numpy()
+    print(mode, "alpha max rel err %.2e  X max abs err %.2e"
+          % (np.max(np.abs(a - a_ref.numpy()) / np.maximum(a_ref.numpy(), 1e-12)), np.abs(X - X_ref).max()))
+    np.testing.assert_allclose(a, a_ref.numpy(), rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(X, X_ref, rtol=0, atol=5e-4)
+
+    # consumer script on the artefacts it just wrote vs the oracle's clustering of the oracle's X
+    NMI, ARI, F1, label, predict = test_mod.calculate_metrics(
+        category="grid", pretrain_embed_dimension=2048, target_embed_dimension=4096,
+        backbone_names=["dino_vitbase8"], layers_to_extract_from=layers, patchsize=3, train_ratio=1.0, tau=1,
+        supervised=mode, dataset="mvtec_ad", output_dir=out)
+    rN, rA, rF, rl, rp = ocluster.calculate_metrics(X_ref, list(test_ds.anomalies))
+    print(mode, "NMI/ARI/F1 ours %.4f %.4f %.4f  oracle %.4f %.4f %.4f" % (NMI, ARI, F1, rN, rA, rF))
+    assert abs(NMI - rN) <= 1e-3 and abs(ARI - rA) <= 1e-3 and abs(F1 - rF) <= 1e-3
+    assert np.array_equal(label, rl)
