@@ -145,9 +145,11 @@ template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetri
 // general (non-symmetric) launches use the LDS-DMA ring kernel unless AC_GEMM=1
 static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream) {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 2; }
-  if (epi.symmetric || v == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
-  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, 8);
+  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
+  if (v == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
+  if (v == 2) return gemm2::launch<EpiPairMin, true, 0>(A, B, M, N, K, epi, stream, 8);
+  if (v == 3) return gemm2::launch<EpiPairMin, true, 1>(A, B, M, N, K, epi, stream, 8);
+  return gemm2::launch<EpiPairMin, true, 2>(A, B, M, N, K, epi, stream, 8);
 }
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {

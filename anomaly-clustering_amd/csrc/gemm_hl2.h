@@ -32,7 +32,7 @@ __device__ inline int tile_off(int row, int lc) { return row * 128 + ((lc ^ ((ro
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <class Epi, bool FLUSH>
+template <class Epi, bool FLUSH, int SCHED>
 __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
                                                      Epi epi) {
@@ -44,6 +44,21 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 
   int tm, tn;
   gemm::raster(blockIdx.x, tiles_m, tiles_n, group_m, tm, tn);
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {
+      // C = C^T on a grid of 256-row x 128-column tiles: in units of 128-blocks a tile holds row
+      // blocks {2tm, 2tm+1} and column block tn; the upper triangle needs the tiles with tn >= 2tm.
+      // Tile row p has Tn - 2p of them; rows p and Tm-1-p together always have 2Tn - 2Tm + 2, so the
+      // launch grid is that folded rectangle and every XCD gets the same amount of work.
+      const int Tm = (M + BM - 1) / BM, Tn = (N + BN - 1) / BN;
+      const int p = tm, c = tn, n1 = Tn - 2 * p;
+      if (c < n1) { tm = p; tn = 2 * p + c; }
+      else {
+        if (2 * p == Tm - 1) return;                // odd Tm: the middle row is paired with itself
+        tm = Tm - 1 - p; tn = 2 * tm + (c - n1);
+      }
+    }
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA map: wave-instruction g (0..47) fills LDS bytes [g*1024, +1024) of a stage:
@@ -91,9 +106,165 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       }
 
   const int nk = K / BK;
-  issue(0);
-  if (nk > 1) issue(1);
+  if constexpr (SCHED == 2) {
+    // ---- staggered schedule with REGISTER staging (global -> VGPR -> ds_write_b128), 2 LDS slots.
+    // Same two-barrier, half-a-stage-apart structure as SCHED 1, but the loads of stage kt+2 are plain
+    // global_load_dwordx4 (a few cycles of issue each) and land in LDS one stage later with 6
+    // ds_write_b128 per thread; an LDS-DMA wave-instruction costs the issuing wave ~100 cycles, 600 per
+    // stage, which made P1 (loads + fragment reads) longer than P2 (24 MFMAs).
+    //   P1(kt): read the 16 fragments of stage kt (slot kt&1); write the staged registers of stage
+    //           kt+1 into slot (kt+1)&1 (last read in P1(kt-1): both groups left it a barrier ago);
+    //           issue the global loads of stage kt+2 into the same registers.
+    //   P2(kt): 24 MFMAs on registers.
+    const bool groupB = wave >= 4;
+    const uint8_t* gsrc[6];
+    int ldst[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int c = j * THREADS + tid;
+      const bool isA = j < 4;
+      const int cc = isA ? c : c - 4 * THREADS;
+      const int row = cc >> 3, lc = cc & 7;
+      const uint8_t* base = isA ? A + (size_t)min(m0 + row, M - 1) * ld : B + (size_t)min(n0 + row, N - 1) * ld;
+      gsrc[j] = base + lc * 16;
+      ldst[j] = (isA ? 0 : A_BYTES) + tile_off(row, lc);
+    }
+    u32x4 st[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) st[j] = *reinterpret_cast<const u32x4*>(gsrc[j]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(smem + ldst[j]) = st[j];
+    if (nk > 1) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) st[j] = *reinterpret_cast<const u32x4*>(gsrc[j] + 128);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // #0: stage 0 visible to everyone
+    asm volatile("" ::: "memory");
+    if (groupB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint8_t* cur = smem + (kt & 1) * STAGE;
+      half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ah[s][t] = *reinterpret_cast<const half8*>(cur + a_off[s][t][0]);
+          al[s][t] = *reinterpret_cast<const half8*>(cur + a_off[s][t][1]);
+          bh[s][t] = *reinterpret_cast<const half8*>(cur + b_off[s][t][0]);
+          bl[s][t] = *reinterpret_cast<const half8*>(cur + b_off[s][t][1]);
+        }
+      if (kt + 1 < nk) {
+        uint8_t* nxt = smem + ((kt + 1) & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<u32x4*>(nxt + ldst[j]) = st[j];
+      }
+      if (kt + 2 < nk) {
+        const size_t ko = (size_t)(kt + 2) * 128;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) st[j] = *reinterpret_cast<const u32x4*>(gsrc[j] + ko);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][mi], bl[s][ni], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][mi], bh[s][ni], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][mi], bh[s][ni], f.acc[mi][ni], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      if (FLUSH && (kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tot.acc[mi][ni][i] += f.acc[mi][ni][i]; f.acc[mi][ni][i] = 0.f; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (!groupB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+  } else {
+    issue(0);
+    if (nk > 1) issue(1);
+  }
 
+  if constexpr (SCHED == 2) {
+  } else if constexpr (SCHED == 1) {
+    // ---- staggered schedule: two barriers per stage, the halves of the workgroup half a stage apart.
+    // A stage is split into P1 = {16 fragment reads, 6 DMA issues of stage kt+2} and P2 = {24 MFMAs on
+    // registers}.  Waves 0-3 (group A) and waves 4-7 (group B; w and w+4 share a SIMD) run the same
+    // code one barrier apart, so on every SIMD one wave is in P2 while its partner is in P1: the matrix
+    // pipe no longer idles while all eight waves issue loads in lockstep.
+    //   barrier #:   0      1        2        3        4
+    //   A:            P1(0) | P2(0)  | P1(1)  | P2(1)  | ...
+    //   B:          (wait)  | P1(0)  | P2(0)  | P1(1)  | ...
+    // Visibility: every wave has waited for its own DMA share of stage kt+1 before the barrier that
+    // precedes group A's P1(kt+1) (A: end of P2(kt), B: end of P1(kt)).  Reuse: the ring slot of stage
+    // kt+2 was last read in P1(kt-1), which both groups have left (lgkmcnt(0) + barrier) before either
+    // issues into it.
+    const bool groupB = wave >= 4;
+    auto wait_share = [&](int kt) {                 // own share of stage kt+1 landed
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // #0: stage 0 visible to everyone
+    asm volatile("" ::: "memory");
+    if (groupB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    for (int kt = 0; kt < nk; ++kt) {
+      const uint8_t* cur = smem + (kt % NSTAGE) * STAGE;
+      half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ah[s][t] = *reinterpret_cast<const half8*>(cur + a_off[s][t][0]);
+          al[s][t] = *reinterpret_cast<const half8*>(cur + a_off[s][t][1]);
+          bh[s][t] = *reinterpret_cast<const half8*>(cur + b_off[s][t][0]);
+          bl[s][t] = *reinterpret_cast<const half8*>(cur + b_off[s][t][1]);
+        }
+      if (kt + 2 < nk) issue(kt + 2);
+      if (groupB) wait_share(kt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][mi], bl[s][ni], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][mi], bh[s][ni], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][mi], bh[s][ni], f.acc[mi][ni], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      if (FLUSH && (kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tot.acc[mi][ni][i] += f.acc[mi][ni][i]; f.acc[mi][ni][i] = 0.f; }
+      }
+      if (!groupB) wait_share(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (!groupB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed for this wave once at most the 6 loads of stage kt+1 are still in flight;
     // the barrier makes every wave's share visible and proves everyone is done reading stage kt-1.
@@ -157,26 +328,48 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     epi.staged(t, m0 + wm * 64, n0 + wn * 64, lane);
+  } else if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {
+      // this wave's 64 rows lie in 128-row block rb, its columns in block cb = tn:
+      // rb < cb: off-diagonal, reduce both ways; rb == cb: diagonal block, one way; rb > cb: the
+      // lower half of a diagonal tile - its mirror image is computed by tile (tm, tn+1)
+      const int rb = 2 * tm + (wm >> 1), cb = tn;
+      __builtin_amdgcn_s_barrier();                 // every wave is done with the ring
+      asm volatile("" ::: "memory");
+      if (rb <= cb) epi(f, m0 + wm * 64, n0 + wn * 64, lane);
+      if (rb < cb)
+        epi.transposed(f, m0 + wm * 64, n0 + wn * 64, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65));
+    } else {
+      epi(f, m0 + wm * 64, n0 + wn * 64, lane);
+    }
   } else {
     epi(f, m0 + wm * 64, n0 + wn * 64, lane);
   }
 }
 
-template <class Epi, bool FLUSH = false>
+template <class Epi, bool FLUSH = false, int SCHED = 0>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 8) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl2: K=%d must be a positive multiple of 32", K);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {                           // folded upper triangle (see the kernel)
+      if (M != N) return ac_fail(AC_EINVAL, "gemm_hl2: symmetric epilogue needs M == N");
+      const int Tm = tiles_m, Tn = tiles_n;
+      tiles_m = (Tm + 1) / 2;
+      tiles_n = 2 * Tn - 2 * Tm + 2;
+    }
+  }
   long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl2: grid too large");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi, FLUSH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi, FLUSH, SCHED>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((kernel<Epi, FLUSH>), dim3((unsigned)total), dim3(THREADS), LDS_BYTES, stream,
+  hipLaunchKernelGGL((kernel<Epi, FLUSH, SCHED>), dim3((unsigned)total), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
                      group_m, epi);
   return ac_check_launch("gemm_hl2");

@@ -16,13 +16,15 @@ constexpr int HD = 64;          // head dim (all DINO ViTs)
 // AC_GEMM=1 selects the first-generation 128x128 register-staged kernel (A/B runs); default: LDS-DMA ring.
 static int gemm_version() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 2; }
+  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
   return v;
 }
 template <class Epi>
 static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
-  return gemm_version() == 1 ? gemm::launch(A, B, M, N, K, epi, stream)
-                             : gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 1) return gemm::launch(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 2) return gemm2::launch<Epi, false, 0>(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 3) return gemm2::launch<Epi, false, 1>(A, B, M, N, K, epi, stream);
+  return gemm2::launch<Epi, false, 2>(A, B, M, N, K, epi, stream);
 }
 
 __host__ __device__ inline int tpad_of(int T) { return (T + 31) / 32 * 32; }
