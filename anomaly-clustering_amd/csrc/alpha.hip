@@ -143,13 +143,14 @@ struct EpiPairMin {
 template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; static constexpr bool kStaged = false; };
 
 // general (non-symmetric) launches use the LDS-DMA ring kernel unless AC_GEMM=1
-static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream) {
+static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream,
+                           int part = 0, int nparts = 1) {
   static int v = -1;
   if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
-  if (v == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
-  if (v == 2) return gemm2::launch<EpiPairMin, true, 0>(A, B, M, N, K, epi, stream, 8);
-  if (v == 3) return gemm2::launch<EpiPairMin, true, 1>(A, B, M, N, K, epi, stream, 8);
-  return gemm2::launch<EpiPairMin, true, 2>(A, B, M, N, K, epi, stream, 8);
+  if (v == 1 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
+  if (v == 2) return gemm2::launch<EpiPairMin, true, 0>(A, B, M, N, K, epi, stream, 8, part, nparts);
+  if (v == 4) return gemm2::launch<EpiPairMin, true, 2>(A, B, M, N, K, epi, stream, 8, part, nparts);
+  return gemm2::launch<EpiPairMin, true, 1>(A, B, M, N, K, epi, stream, 8, part, nparts);
 }
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
@@ -241,12 +242,14 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
 // Staged form of the same computation (pack -> min-d2 GEMM -> reduce) for callers that keep the
 // packed operands resident across calls or want to time the MFMA kernel on its own.
 extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64_t nk, const void* Zq_hl,
-                                     const float* q_sq, int64_t nq, int P, int D, uint32_t* minbuf, void* stream) {
+                                     const float* q_sq, int64_t nq, int P, int D, uint32_t* minbuf, int part,
+                                     int nparts, void* stream) {
   AC_REQUIRE(Zk_hl && k_sq && Zq_hl && q_sq && minbuf, "ac_pair_min_sq_packed: null pointer");
+  AC_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "ac_pair_min_sq_packed: bad part %d/%d", part, nparts);
   AC_REQUIRE(nq > 0 && nk > 0 && P > 0 && D > 0 && D % 32 == 0, "ac_pair_min_sq_packed: bad shape");
   AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_sq_packed: too many patches");
   EpiPairMin epi{k_sq, q_sq, minbuf, (int)(nk * P), (int)(nq * P), P, Zk_hl == Zq_hl && nk == nq};
-  return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream));
+  return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), part, nparts);
 }
 
 extern "C" int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,

@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <class Epi, bool FLUSH, int SCHED>
 __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
-                                                     Epi epi) {
+                                                     int block_offset, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   const int r = lane & 31, h = lane >> 5;
 
   int tm, tn;
-  gemm::raster(blockIdx.x, tiles_m, tiles_n, group_m, tm, tn);
+  gemm::raster(blockIdx.x + block_offset, tiles_m, tiles_n, group_m, tm, tn);
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {
       // C = C^T on a grid of 256-row x 128-column tiles: in units of 128-blocks a tile holds row
@@ -349,9 +349,13 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 
 template <class Epi, bool FLUSH = false, int SCHED = 0>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                  int group_m = 8) {
+                  int group_m = 8, int part = 0, int nparts = 1) {
+  // part / nparts: launch only the part-th of nparts contiguous slices of the block-id space (slice
+  // boundaries are multiples of 8 so the XCD round-robin stays aligned) - used to split one
+  // symmetric all-pairs problem over several GPUs.
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl2: K=%d must be a positive multiple of 32", K);
+  if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl2: bad part %d/%d", part, nparts);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {                           // folded upper triangle (see the kernel)
@@ -369,9 +373,12 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((kernel<Epi, FLUSH, SCHED>), dim3((unsigned)total), dim3(THREADS), LDS_BYTES, stream,
+  long long lo = (total * part / nparts) & ~7LL;
+  long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
+  if (hi <= lo) return AC_OK;
+  hipLaunchKernelGGL((kernel<Epi, FLUSH, SCHED>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
-                     group_m, epi);
+                     group_m, (int)lo, epi);
   return ac_check_launch("gemm_hl2");
 }
 

@@ -45,7 +45,7 @@ SIGNATURES = {
     "ac_adaptive_avg_pool_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "ac_pair_min_dist_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
     "ac_pair_min_dist": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
-    "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),
     "ac_pair_reduce": (_i, [_vp, _i64, _i64, _i, _i, _i64, _vp, _vp]),
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
@@ -302,11 +302,42 @@ def pair_min_dist_staged(Zq, Zk, reduce, self_offset=0, minbuf_budget=1 << 30):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         _check(lib().ac_pair_min_sq_packed(hk.data_ptr(), sk.data_ptr(), nk, hq[q0 * P:].data_ptr(),
-                                           sq[q0 * P:].data_ptr(), qn, P, D, mb.data_ptr(), st))
+                                           sq[q0 * P:].data_ptr(), qn, P, D, mb.data_ptr(), 0, 1, st))
         if kernel_events is not None:
             ev1.record()
             kernel_events.append(("pair_min_sq", ev0, ev1, nk, qn, P, D))
         _check(lib().ac_pair_reduce(mb.data_ptr(), nk, qn, P, reduce, self_offset + q0, w[q0:].data_ptr(), st))
+    return w
+
+
+def pair_min_sq_part(Z, part=0, nparts=1):
+    """One slice of the SYMMETRIC all-pairs problem on Z [N, P, D] (keys == queries): returns
+    minbuf fp32 [N, N*P] with minbuf[j][i*P + p] = min_q ||Z[i][p] - Z[j][q]||^2 for the (i, j) tile
+    pairs of this slice and +inf elsewhere.  The element-wise minimum over all `nparts` slices (e.g.
+    a MIN all-reduce across ranks) is the complete matrix; `pair_reduce` turns it into w."""
+    _dev(Z, torch.float32, "Z")
+    N, P, D = Z.shape
+    hk, sk = pack_hl32(Z.reshape(N * P, D), want_sqnorm=True)
+    minbuf = torch.full((N, N * P), float("inf"), dtype=torch.float32, device=Z.device)
+    if kernel_events is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _check(lib().ac_pair_min_sq_packed(hk.data_ptr(), sk.data_ptr(), N, hk.data_ptr(), sk.data_ptr(), N, P, D,
+                                       minbuf.data_ptr(), part, nparts, _stream()))
+    if kernel_events is not None:
+        ev1.record()
+        kernel_events.append(("pair_min_sq", ev0, ev1, N, N / float(nparts), P, D))
+    return minbuf
+
+
+def pair_reduce(minbuf, P, reduce, self_first=0):
+    """minbuf fp32 [nk, nq*P] (squared mins) -> w fp32 [nq, P]: mean over key images != self_first + i
+    of the square roots, or the square root of the min over all key images."""
+    p = _dev(minbuf, torch.float32, "minbuf")
+    nk, cols = minbuf.shape
+    nq = cols // P
+    w = torch.empty((nq, P), dtype=torch.float32, device=minbuf.device)
+    _check(lib().ac_pair_reduce(p, nk, nq, P, reduce, self_first, w.data_ptr(), _stream()))
     return w
 
 

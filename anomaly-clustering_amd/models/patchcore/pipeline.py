@@ -23,6 +23,9 @@ import torch
 import torch.distributed as dist
 
 
+SYMMETRIC_MINBUF_BYTES = 1 << 30     # largest [N, N*P] fp32 matrix the partitioned symmetric path may allocate
+
+
 def shard_bounds(n, world):
     """Contiguous blocks of ceil(n/world) images: [(lo, hi)] per rank (trailing ranks may be empty)."""
     per = (n + world - 1) // world if world > 0 else n
@@ -43,6 +46,12 @@ class HipOps:
 
     def pair_min_dist(self, Zq, Zk, reduce, self_offset):
         return self.acnative.pair_min_dist_staged(Zq, Zk, reduce, self_offset)
+
+    def pair_min_sq_part(self, Z, part, nparts):
+        return self.acnative.pair_min_sq_part(Z, part, nparts)
+
+    def pair_reduce(self, minbuf, P, reduce, self_first):
+        return self.acnative.pair_reduce(minbuf, P, reduce, self_first)
 
     def alpha_softmax(self, w, tau, k):
         return self.acnative.alpha_softmax(w, tau, k)
@@ -124,7 +133,16 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         alpha_loc = ops.alpha_softmax(w_loc, tau, k)
     elif supervised == "unsupervised":
         Z_all = all_gather_rows(Z_loc, counts, group)
-        w_loc = ops.pair_min_dist(Z_loc, Z_all, 0, lo)
+        P = Z_all.shape[1]
+        if world > 1 and n * n * P * 4 <= SYMMETRIC_MINBUF_BYTES:
+            # every rank takes 1/world of the UPPER-TRIANGLE tiles of the symmetric N*P x N*P problem
+            # (each tile reduced in both directions), then one MIN all-reduce of the [N, N*P] matrix of
+            # per-(key image, query patch) minima completes it: half the MFMA work of "my queries x all keys"
+            minbuf = ops.pair_min_sq_part(Z_all, rank, world)
+            dist.all_reduce(minbuf, op=dist.ReduceOp.MIN, group=group)
+            w_loc = ops.pair_reduce(minbuf[:, lo * P: hi * P].contiguous(), P, 0, lo)
+        else:
+            w_loc = ops.pair_min_dist(Z_loc, Z_all, 0, lo)
         alpha_loc = ops.alpha_softmax(w_loc, tau, k)
     else:                                                              # "average" (main.py:290-291)
         alpha_loc = torch.ones(Z_loc.shape[0], Z_loc.shape[1], device=Z_loc.device) / Z_loc.shape[1]

@@ -136,9 +136,15 @@ int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, i
  *   ac_pair_min_sq_packed: minbuf[j][i*P + p] = min(minbuf, min_q d2(Zq[i][p], Zk[j][q])) as the
  *       IEEE bits of a non-negative float; the caller presets minbuf (uint32 [nk][nq*P]) to +inf
  *       (0x7f800000).  This call launches exactly one kernel (the MFMA GEMM with the fused min).
+ *       When Zq and Zk are the same packed buffer (nq == nk) the problem is symmetric and only the
+ *       upper triangle of tiles is computed, each reduced in both directions.
+ *       part / nparts (0 / 1 = everything): compute only the part-th of nparts equal slices of the
+ *       tile grid - several GPUs each take a slice of one symmetric problem into their own minbuf and
+ *       combine with an element-wise MIN all-reduce.
  *   ac_pair_reduce: w[i][p] = mean_{j != self_first + i} sqrt(minbuf[j][..]) or sqrt(min_j ..). */
 int ac_pair_min_sq_packed(const void* Zk_hl32, const float* k_sqnorm, int64_t nk, const void* Zq_hl32,
-                          const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, void* stream);
+                          const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, int part,
+                          int nparts, void* stream);
 int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,
                    float* w, void* stream);
 

@@ -137,6 +137,39 @@ def test_query_shard_matches_whole(dev):
     assert np.abs(general.cpu().numpy() - ref).max() <= 2e-5
 
 
+def test_partitioned_symmetric_slices_combine_to_the_whole(dev):
+    """What rank r of G computes in the multi-GPU unsupervised path: slice r of the upper-triangle
+    tiles into its own minbuf.  The element-wise MIN over the G slices (the all-reduce) must equal
+    the single-launch matrix bit for bit, for G that do and do not divide the tile count."""
+    import acnative
+    Zs, _ = clustered_embeddings(5, 784, 256, 3, salt=55)          # 3920 rows: 16 x 31 tiles, ragged edge
+    Z = torch.from_numpy(Zs).to(dev)
+    whole = acnative.pair_min_sq_part(Z, 0, 1)
+    assert torch.isfinite(whole).all()
+    for G in (2, 3, 8):
+        parts = [acnative.pair_min_sq_part(Z, r, G) for r in range(G)]
+        combined = torch.stack(parts).min(0)[0]
+        assert torch.equal(combined, whole), G
+        assert sum(int(torch.isfinite(p).sum()) for p in parts) >= whole.numel()     # slices cover everything
+    w = acnative.pair_reduce(whole, 784, acnative.REDUCE_MEAN_OTHERS, 0)
+    assert torch.equal(w, acnative.pair_min_dist_staged(Z, Z, acnative.REDUCE_MEAN_OTHERS))
+    w_part = acnative.pair_reduce(whole[:, 784:3 * 784].contiguous(), 784, acnative.REDUCE_MEAN_OTHERS, 1)
+    assert torch.equal(w_part, w[1:3])
+
+
+def test_query_chunking_with_a_small_minbuf_budget(dev):
+    """N large enough that minbuf must be chunked over the queries (config 5's code path), forced
+    here with a tiny budget: chunked == unchunked."""
+    import acnative
+    Zs, _ = clustered_embeddings(6, 100, 128, 3, salt=56)
+    Z = torch.from_numpy(Zs).to(dev)
+    ref = acnative.pair_min_dist_staged(Z, Z.clone(), acnative.REDUCE_MEAN_OTHERS)
+    small = acnative.pair_min_dist_staged(Z, Z.clone(), acnative.REDUCE_MEAN_OTHERS, minbuf_budget=6 * 100 * 4 * 2)
+    assert torch.equal(ref, small)
+    sup = acnative.pair_min_dist_staged(Z[:4], Z[2:].contiguous(), acnative.REDUCE_MIN_ALL, minbuf_budget=4 * 100 * 4)
+    assert torch.equal(sup, acnative.pair_min_dist(Z[:4].contiguous(), Z[2:].contiguous(), acnative.REDUCE_MIN_ALL))
+
+
 def test_ragged_edges_vs_oracle(dev):
     """P not a multiple of anything, nq != nk, D = 32 (one K step), single-image banks."""
     import acnative

@@ -28,13 +28,32 @@ class ToyOps:
         return (flat * 1.5 + flat.roll(1, dims=2) * 0.5).contiguous()
 
     def pair_min_dist(self, Zq, Zk, reduce, self_offset):
-        from oracle import alpha as oa
         out = []
         for i in range(Zq.shape[0]):
-            cols = [oa.pair_min_distance(Zq[i], Zk[j]) for j in range(Zk.shape[0]) if not (reduce == 0 and j == i + self_offset)]
+            cols = [(torch.cdist(Zq[i], Zk[j]).min(1)[0] ** 2).sqrt() for j in range(Zk.shape[0])
+                    if not (reduce == 0 and j == i + self_offset)]
             cols = torch.stack(cols, 1)
             out.append(cols.mean(1) if reduce == 0 else cols.min(1)[0])
         return torch.stack(out) if out else torch.zeros(0, Zq.shape[1])
+
+    def pair_min_sq_part(self, Z, part, nparts):
+        """Slice = the key images j with j % nparts == part (any disjoint cover works for the MIN all-reduce)."""
+        n, P, _ = Z.shape
+        out = torch.full((n, n * P), float("inf"))
+        for j in range(part, n, nparts):
+            for i in range(n):
+                out[j, i * P:(i + 1) * P] = torch.cdist(Z[i], Z[j]).min(1)[0] ** 2
+        return out
+
+    def pair_reduce(self, minbuf, P, reduce, self_first):
+        nk, cols = minbuf.shape
+        d = minbuf.sqrt().reshape(nk, cols // P, P)
+        out = []
+        for i in range(cols // P):
+            rows = [d[j, i] for j in range(nk) if not (reduce == 0 and j == i + self_first)]
+            rows = torch.stack(rows, 1)
+            out.append(rows.mean(1) if reduce == 0 else rows.min(1)[0])
+        return torch.stack(out)
 
     def alpha_softmax(self, w, tau, k):
         from oracle import alpha as oa
