@@ -148,9 +148,7 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   static int v = -1;
   if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
   if (v == 1 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
-  if (v == 2) return gemm2::launch<EpiPairMin, true, 0>(A, B, M, N, K, epi, stream, 8, part, nparts);
-  if (v == 4) return gemm2::launch<EpiPairMin, true, 2>(A, B, M, N, K, epi, stream, 8, part, nparts);
-  return gemm2::launch<EpiPairMin, true, 1>(A, B, M, N, K, epi, stream, 8, part, nparts);
+  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, 8, part, nparts);
 }
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {

@@ -22,9 +22,7 @@ static int gemm_version() {
 template <class Epi>
 static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
   if (gemm_version() == 1) return gemm::launch(A, B, M, N, K, epi, stream);
-  if (gemm_version() == 2) return gemm2::launch<Epi, false, 0>(A, B, M, N, K, epi, stream);
-  if (gemm_version() == 3) return gemm2::launch<Epi, false, 1>(A, B, M, N, K, epi, stream);
-  return gemm2::launch<Epi, false, 2>(A, B, M, N, K, epi, stream);
+  return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream);
 }
 
 __host__ __device__ inline int tpad_of(int T) { return (T + 31) / 32 * 32; }
