@@ -58,76 +58,69 @@ struct EpiPairMin {
   const float* qry_sq;   // [N]
   unsigned* minbuf;      // [n_key_images][N]
   int M, N, P;
-  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
-    const int r = lane & 31, h = lane >> 5;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
     if (m_wave >= M) return;                      // wave-uniform
     const int m_end = min(m_wave + 64, M);
-    float ksq[2][16];
+    float ksq[F::NT][F::NR];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        ksq[mi][i] = key_sq[min(row, M - 1)];
-      }
+      for (int i = 0; i < F::NR; ++i) ksq[mi][i] = key_sq[min(m_wave + F::row(mi, i, lane), M - 1)];
     const int img_first = m_wave / P, img_last = (m_end - 1) / P;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n_wave + ni * 32 + r;
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
       const float qs = qry_sq[min(col, N - 1)];
-      float d2[2][16];
+      float d2[F::NT][F::NR];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i)   // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
+        for (int i = 0; i < F::NR; ++i)   // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
           d2[mi][i] = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
       for (int img = img_first; img <= img_last; ++img) {   // wave-uniform trip count (<= 2 when P >= 64)
         const int lo = img * P, hi = min(lo + P, m_end);
         float mn = __builtin_inff();
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          for (int i = 0; i < F::NR; ++i) {
+            int row = m_wave + F::row(mi, i, lane);
             mn = (row >= lo && row < hi) ? fminf(mn, d2[mi][i]) : mn;
           }
-        mn = fminf(mn, __shfl_xor(mn, 32, 64));
-        if (h == 0 && col < N) atomicMin(minbuf + (size_t)img * N + col, __float_as_uint(mn));
+        mn = F::min_over_row_groups(mn);
+        if (F::first_row_group(lane) && col < N) atomicMin(minbuf + (size_t)img * N + col, __float_as_uint(mn));
       }
     }
   }
 
   // Symmetric case (keys == queries, M == N): the same tile read the other way - the block's ROWS
-  // are the query patches, its COLUMNS the key patches.  The wave's 64x32 slab of d2 goes through
-  // LDS transposed ([column][row], 65-float pitch), then lane l owns row l and takes the min over
-  // the columns of each key image.
-  __device__ void transposed(const gemm::Frag& f, int m_wave, int n_wave, int lane, float* tb) const {
-    const int r = lane & 31, h = lane >> 5;
+  // are the query patches, its COLUMNS the key patches.  One TW-column slab of the wave's d2 at a time
+  // goes through LDS transposed ([column][row], 65-float pitch), then lane l owns row l and takes the
+  // min over the columns of each key image.
+  template <class F>
+  __device__ void transposed(const F& f, int m_wave, int n_wave, int lane, float* tb) const {
     if (m_wave >= M || n_wave >= N) return;       // wave-uniform
-    float ksq[2][16];
+    float ksq[F::NT][F::NR];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        ksq[mi][i] = key_sq[min(row, M - 1)];
-      }
+      for (int i = 0; i < F::NR; ++i) ksq[mi][i] = key_sq[min(m_wave + F::row(mi, i, lane), M - 1)];
     const int my_row = m_wave + lane;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int c_base = n_wave + ni * 32;
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int c_base = n_wave + ni * F::TW;
       if (c_base >= N) break;                      // wave-uniform
-      const int col = c_base + r;
-      const float qs = qry_sq[min(col, N - 1)];
+      const int cl = F::col(ni, lane) - ni * F::TW;
+      const float qs = qry_sq[min(c_base + cl, N - 1)];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          tb[r * 65 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] =
-              fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+        for (int i = 0; i < F::NR; ++i)
+          tb[cl * 65 + F::row(mi, i, lane)] = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      const int c_end = min(c_base + 32, N);
+      const int c_end = min(c_base + F::TW, N);
       for (int img = c_base / P; img <= (c_end - 1) / P; ++img) {   // wave-uniform, <= 2 trips when P >= 32
         const int lo = max(img * P, c_base) - c_base, hi = min((img + 1) * P, c_end) - c_base;
         float mn = __builtin_inff();

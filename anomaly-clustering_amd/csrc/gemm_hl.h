@@ -44,9 +44,34 @@ __device__ inline void raster(int id, int tiles_m, int tiles_n, int group_m, int
   tm = first + (within - tn * gsz);
 }
 
-struct Frag {   // register image of one wave's 64x64 accumulator
+// Register image of one wave's 64x64 accumulator, for the two fp16 MFMA shapes.  Epilogues are
+// written against this interface (NT tiles per side, NR registers per tile, row()/col() of an element,
+// min_over_row_groups()) so the same epilogue serves both kernels:
+//   FragT<32>: v_mfma_f32_32x32x16_f16, 2x2 tiles, C/D map col = lane&31, row = (i&3)+8(i>>2)+4(lane>>5)
+//   FragT<16>: v_mfma_f32_16x16x32_f16, 4x4 tiles, C/D map col = lane&15, row = 4(lane>>4)+i
+// (the chip sustains a ~14 % higher clock on the 16x16x32 shape: csrc/probe/mfma_rate.hip)
+template <int SHAPE> struct FragT;
+template <> struct FragT<32> {
+  static constexpr int NT = 2, NR = 16, TW = 32;
   f32x16 acc[2][2];
+  static __device__ inline int row(int mi, int i, int lane) { return mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+  static __device__ inline int col(int ni, int lane) { return ni * 32 + (lane & 31); }
+  // lanes with equal col() hold different rows: combine them (the result is valid in every lane)
+  static __device__ inline float min_over_row_groups(float v) { return fminf(v, __shfl_xor(v, 32, 64)); }
+  static __device__ inline bool first_row_group(int lane) { return lane < 32; }
 };
+template <> struct FragT<16> {
+  static constexpr int NT = 4, NR = 4, TW = 16;
+  f32x4 acc[4][4];
+  static __device__ inline int row(int mi, int i, int lane) { return mi * 16 + 4 * (lane >> 4) + i; }
+  static __device__ inline int col(int ni, int lane) { return ni * 16 + (lane & 15); }
+  static __device__ inline float min_over_row_groups(float v) {
+    v = fminf(v, __shfl_xor(v, 16, 64));
+    return fminf(v, __shfl_xor(v, 32, 64));
+  }
+  static __device__ inline bool first_row_group(int lane) { return lane < 16; }
+};
+using Frag = FragT<32>;
 
 // Epilogues that can exploit C = C^T (A and B are the same matrix) specialise this to true and
 // provide `bool symmetric` plus `transposed(frag, m_wave, n_wave, lane, float* lds_scratch)`:

@@ -13,7 +13,7 @@
 //   * ring of 3 stages (3 x 48 KB); the loads of stage t+2 are issued while stage t is multiplied;
 //     waits are counted (s_waitcnt vmcnt(6): one stage's 6 wave-instructions stay in flight) and
 //     barriers are raw s_barrier (a __syncthreads() would drain the DMA queue);
-//   * STAGGER: a stage is split into P1 = {16 fragment reads, 6 DMA issues} and P2 = {24 MFMAs on
+//   * STAGGER: a stage is split into P1 = {16 fragment reads, 6 DMA issues} and P2 = {48 MFMAs on
 //     registers}, separated by barriers; waves 0-3 and waves 4-7 (w and w+4 share a SIMD) run the
 //     same code one barrier apart, so on every SIMD one wave multiplies while its partner loads:
 //       barrier #:   0      1        2        3
@@ -35,7 +35,7 @@
 namespace gemm2 {
 
 using gemm::EpiTraits;
-using gemm::Frag;
+using Frag = gemm::FragT<16>;   // v_mfma_f32_16x16x32_f16: 4x4 tiles of 16x16 per wave
 
 constexpr int BM = 256, BN = 128, BK = 32, NSTAGE = 3, THREADS = 512;
 constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 KB
@@ -78,22 +78,20 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
   const bool groupB = wave >= 4;
   const size_t ld = (size_t)K * 4;
   const int nk = K / BK;
 
-  // per-lane fragment offsets inside a stage: [kstep][tile][plane]
-  int a_off[2][2][2], b_off[2][2][2];
+  // per-lane fragment offsets inside a stage: [16-row tile][plane].  One 16x16x32 MFMA consumes the
+  // whole 32-deep stage: lane l holds row l&15, k = 8(l>>4) .. +7, i.e. 16-byte chunk l>>4 of the row.
+  int a_off[4][2], b_off[4][2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        a_off[s][t][p] = tile_off(wm * 64 + t * 32 + r, p * 4 + s * 2 + h);
-        b_off[s][t][p] = A_BYTES + tile_off(wn * 64 + t * 32 + r, p * 4 + s * 2 + h);
-      }
+    for (int p = 0; p < 2; ++p) {
+      a_off[t][p] = tile_off(wm * 64 + t * 16 + (lane & 15), p * 4 + (lane >> 4));
+      b_off[t][p] = A_BYTES + tile_off(wn * 64 + t * 16 + (lane & 15), p * 4 + (lane >> 4));
+    }
 
   // ---- DMA map: wave-instruction g (0..47) fills LDS bytes [g*1024, +1024) of a stage:
   // g < 32 -> rows 8g..8g+7 of the A tile, else rows 8(g-32).. of the B tile.  Wave w issues
@@ -137,11 +135,11 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     const int m0 = tm * BM, n0 = tn * BN, tm_cur = tm, tn_cur = tn;
     Frag f, tot;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { f.acc[mi][ni][i] = 0.f; if (FLUSH) tot.acc[mi][ni][i] = 0.f; }
+        for (int i = 0; i < 4; ++i) { f.acc[mi][ni][i] = 0.f; if (FLUSH) tot.acc[mi][ni][i] = 0.f; }
 
     wait_one_stage_in_flight(nk > 1);
     barrier();                                      // #0: stage 0 visible to everyone
@@ -149,16 +147,14 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     for (int kt = 0; kt < nk; ++kt) {
       // ---------------- P1(kt)
       const uint8_t* cur = smem + (kt % NSTAGE) * STAGE;
-      half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+      half8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          ah[s][t] = *reinterpret_cast<const half8*>(cur + a_off[s][t][0]);
-          al[s][t] = *reinterpret_cast<const half8*>(cur + a_off[s][t][1]);
-          bh[s][t] = *reinterpret_cast<const half8*>(cur + b_off[s][t][0]);
-          bl[s][t] = *reinterpret_cast<const half8*>(cur + b_off[s][t][1]);
-        }
+      for (int t = 0; t < 4; ++t) {
+        ah[t] = *reinterpret_cast<const half8*>(cur + a_off[t][0]);
+        al[t] = *reinterpret_cast<const half8*>(cur + a_off[t][1]);
+        bh[t] = *reinterpret_cast<const half8*>(cur + b_off[t][0]);
+        bl[t] = *reinterpret_cast<const half8*>(cur + b_off[t][1]);
+      }
       if (kt + 2 < nk) issue(kt + 2);
       if (groupB) wait_one_stage_in_flight(kt + 2 < nk);      // own share of stage kt+1 landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -167,24 +163,22 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       // ---------------- P2(kt)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][mi], bl[s][ni], f.acc[mi][ni], 0, 0, 0);
-            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][mi], bh[s][ni], f.acc[mi][ni], 0, 0, 0);
-            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][mi], bh[s][ni], f.acc[mi][ni], 0, 0, 0);
-          }
+        for (int ni = 0; ni < 4; ++ni) {
+          f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], f.acc[mi][ni], 0, 0, 0);
+          f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
+          f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
+        }
       __builtin_amdgcn_s_setprio(0);
       // Two-level accumulation (see gemm_hl.h): flush the MFMA accumulator every 512 k-terms.
       if (FLUSH && (kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { tot.acc[mi][ni][i] += f.acc[mi][ni][i]; f.acc[mi][ni][i] = 0.f; }
+            for (int i = 0; i < 4; ++i) { tot.acc[mi][ni][i] += f.acc[mi][ni][i]; f.acc[mi][ni][i] = 0.f; }
       }
       if (!groupB) wait_one_stage_in_flight(kt + 2 < nk);
       __builtin_amdgcn_sched_barrier(0);
@@ -193,11 +187,11 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     if (!groupB) barrier();                         // both groups are past their last ring read
     if (FLUSH) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) f.acc[mi][ni][i] += tot.acc[mi][ni][i];
+          for (int i = 0; i < 4; ++i) f.acc[mi][ni][i] += tot.acc[mi][ni][i];
     }
 
     // next tile: its first two stages go out before this tile's epilogue (ring slots 0/1 are free;
@@ -212,12 +206,12 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     if constexpr (EpiTraits<Epi>::kStaged) {
       float* t = reinterpret_cast<float*>(smem) + wave * (64 * gemm::EPI_PITCH);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            t[(mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * gemm::EPI_PITCH + ni * 32 + r] = f.acc[mi][ni][i];
+          for (int i = 0; i < 4; ++i)
+            t[Frag::row(mi, i, lane) * gemm::EPI_PITCH + Frag::col(ni, lane)] = f.acc[mi][ni][i];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       epi.staged(t, m_wave, n_wave, lane);

@@ -59,18 +59,18 @@ __global__ void set_cls_kernel(const float* __restrict__ cls, const float* __res
 // rows = patches (b*G*G + p), cols = embedding channel: x[b][1+p][col] = acc + bias + pos[1+p]
 struct EpiPatchEmbed {
   const float* bias; const float* pos; float* x; int M, N, PP, T;
-  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
-    const int r = lane & 31, h = lane >> 5;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n_wave + ni * 32 + r;
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
       if (col >= N) continue;
       const float bc = bias[col];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        for (int i = 0; i < F::NR; ++i) {
+          int row = m_wave + F::row(mi, i, lane);
           int rc = min(row, M - 1);
           int b = rc / PP, p = rc - b * PP;
           float pv = pos[(size_t)(1 + p) * N + col];          // unconditional load (see EpiResidual)
@@ -155,20 +155,20 @@ __device__ inline void store_hl32_line(uint8_t* line, const float* v) {
 // q,k: rows = tokens (b*T + t), cols in [0, 2C): dest hl32 [which][B*H][Tpad][64]
 struct EpiQK {
   const float* bias; uint8_t* q; uint8_t* k; int M, C, T, Tpad, H;
-  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
-    const int r = lane & 31, h = lane >> 5;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n_wave + ni * 32 + r;          // 32-aligned group: one (which, head, half-of-head)
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
       if (col >= 2 * C) continue;
       const int which = col / C, fcol = col - which * C, head = fcol >> 6, d = fcol & 63;
       uint8_t* base = (which ? k : q);
       const float bc = bias[col];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        for (int i = 0; i < F::NR; ++i) {
+          int row = m_wave + F::row(mi, i, lane);
           if (row < M) {
             int b = row / T, t = row - b * T;
             float v = f.acc[mi][ni][i] + bc;
@@ -202,18 +202,18 @@ template <> struct gemm::EpiTraits<EpiQK> { static constexpr bool kSymmetric = f
 // dest hl32 [B*H][64][Tpad] (K axis = token), so consecutive lanes write consecutive halves.
 struct EpiVt {
   const float* bias; uint8_t* vt; int C, NT, T, Tpad, H;   // bias already offset to the v third
-  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
-    const int r = lane & 31, h = lane >> 5;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n_wave + ni * 32 + r;
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
       if (col >= NT) continue;
       const int b = col / T, t = col - b * T;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        for (int i = 0; i < F::NR; ++i) {
+          int row = m_wave + F::row(mi, i, lane);
           if (row < C) {
             int head = row >> 6, d = row & 63;
             float v = f.acc[mi][ni][i] + bias[row];
@@ -230,28 +230,26 @@ struct EpiVt {
 // out[m][col] = acc + bias[col] + res[m][col]   (fp32; out may alias res)
 struct EpiResidual {
   const float* bias; const float* res; float* out; int M, N;
-  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
-    const int r = lane & 31, h = lane >> 5;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n_wave + ni * 32 + r;
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
       if (col >= N) continue;
       const float bc = bias[col];
-      // all 32 residual loads first, unconditionally (row clamped): a load under `if (row < M)`
-      // makes hipcc branch and wait vmcnt(0) per element - 64 serial round trips per wave
-      float rv[2][16];
+      // all residual loads of this column first, unconditionally (row clamped): a load under
+      // `if (row < M)` makes hipcc branch and wait vmcnt(0) per element - serial round trips
+      float rv[F::NT][F::NR];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = min(m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, M - 1);
-          rv[mi][i] = res[(size_t)row * N + col];
-        }
+        for (int i = 0; i < F::NR; ++i)
+          rv[mi][i] = res[(size_t)min(m_wave + F::row(mi, i, lane), M - 1) * N + col];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        for (int i = 0; i < F::NR; ++i) {
+          int row = m_wave + F::row(mi, i, lane);
           if (row < M) out[(size_t)row * N + col] = rv[mi][i] + (f.acc[mi][ni][i] + bc);
         }
     }
@@ -277,21 +275,20 @@ __device__ inline float gelu_erf(float v) {
 // g = gelu(acc + bias) (exact erf form, nn.GELU default) -> hl32 [M, N]
 struct EpiGeluHl {
   const float* bias; uint8_t* out; int M, N;
-  __device__ void operator()(const gemm::Frag& f, int m_wave, int n_wave, int lane) const {
-    const int r = lane & 31, h = lane >> 5;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n_wave + ni * 32 + r;
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
       if (col >= N) continue;
       const float bc = bias[col];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int row = m_wave + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        for (int i = 0; i < F::NR; ++i) {
+          int row = m_wave + F::row(mi, i, lane);
           if (row < M) {
-            float v = f.acc[mi][ni][i] + bc;
-            v = gelu_erf(v);
+            float v = gelu_erf(f.acc[mi][ni][i] + bc);
             _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
             uint8_t* p = out + (size_t)row * N * 4 + (col >> 5) * 128 + (col & 31) * 2;
             *reinterpret_cast<_Float16*>(p) = hi;
