@@ -328,8 +328,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
                                                         const uint8_t* __restrict__ Vt, uint8_t* __restrict__ O,
                                                         int T, int Tpad, int H, float scale) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[ATT_LDS];
-  uint8_t* Ks = lds;             // [32 keys][256 B], 16-B slots XOR (row & 15)
-  uint8_t* Vs = lds + 8192;      // [64 d][128 B],   16-B slots XOR ((row >> 1) & 7)
+  // per buffer: K tile [32 keys][256 B] (16-byte slots XOR (row & 15)) then V^T tile [64 d][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
   const int q0 = blockIdx.x * ATT_Q + wave * 32;
@@ -355,18 +354,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
   const uint8_t* Kbase = K + (size_t)bh * Tpad * (HD * 4);
   const uint8_t* Vbase = Vt + (size_t)bh * HD * ((size_t)Tpad * 4);
   const int ntiles = (T + ATT_KT - 1) / ATT_KT;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int key0 = kt * ATT_KT;
-    __syncthreads();                       // previous tile fully consumed
+  // One K / V^T tile in LDS at a time.  (A register-prefetched double buffer was tried: +16 VGPRs took
+  // the kernel from 3 to 2 waves per SIMD and it ran 7 % slower; other workgroups cover the load latency.)
+  u32x4 pk[2], pv[2];
+  auto gload = [&](int kt) {
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       int row = (tid >> 4) + rep * 16, slot = tid & 15;
-      u32x4 v = *reinterpret_cast<const u32x4*>(Kbase + (size_t)(key0 + row) * (HD * 4) + slot * 16);
-      *reinterpret_cast<u32x4*>(Ks + row * 256 + ((slot ^ (row & 15)) << 4)) = v;
+      pk[rep] = *reinterpret_cast<const u32x4*>(Kbase + (size_t)(kt * ATT_KT + row) * (HD * 4) + slot * 16);
       int vrow = (tid >> 3) + rep * 32, vslot = tid & 7;
-      u32x4 w = *reinterpret_cast<const u32x4*>(Vbase + (size_t)vrow * ((size_t)Tpad * 4) + (size_t)kt * 128 + vslot * 16);
-      *reinterpret_cast<u32x4*>(Vs + vrow * 128 + ((vslot ^ ((vrow >> 1) & 7)) << 4)) = w;
+      pv[rep] = *reinterpret_cast<const u32x4*>(Vbase + (size_t)vrow * ((size_t)Tpad * 4) + (size_t)kt * 128 + vslot * 16);
     }
+  };
+  auto lstore = [&](int buf) {
+    uint8_t* Kb = lds + buf * 16384;
+    uint8_t* Vb = Kb + 8192;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      int row = (tid >> 4) + rep * 16, slot = tid & 15;
+      *reinterpret_cast<u32x4*>(Kb + row * 256 + ((slot ^ (row & 15)) << 4)) = pk[rep];
+      // V^T image: 8-byte granule g of row d lives at granule g ^ ((d>>1)&15): conflict-free ds_read_b64
+      // for the 32 rows a lane group reads.  A 16-byte store covers granules 2j, 2j+1: they stay in one
+      // 16-byte slot, swapped when the XOR value is odd.
+      int vrow = (tid >> 3) + rep * 32, vslot = tid & 7, x = (vrow >> 1) & 15;
+      u32x4 w = pv[rep];
+      if (x & 1) { u32x4 t = w; w[0] = t[2]; w[1] = t[3]; w[2] = t[0]; w[3] = t[1]; }
+      *reinterpret_cast<u32x4*>(Vb + vrow * 128 + ((vslot ^ (x >> 1)) << 4)) = w;
+    }
+  };
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * ATT_KT;
+    const uint8_t* Ks = lds;
+    const uint8_t* Vs = Ks + 8192;
+    __syncthreads();                       // previous tile fully consumed
+    gload(kt);
+    lstore(0);
     __syncthreads();
 
     // S^T tile [32 keys x 32 queries]
@@ -419,14 +441,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
     // O^T += V^T P^T ; A fragment element j <-> key 16s + 8(j>>2) + 4h + (j&3)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int d = mt * 32 + r, sw = (d >> 1) & 7;
+      const int d = mt * 32 + r, sw = (d >> 1) & 15;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int g0 = 4 * s + h, g1 = g0 + 2;                 // 8-byte granules of the hi part
-        half4 a0 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g0 >> 1) ^ sw) << 4) + (g0 & 1) * 8);
-        half4 a1 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g1 >> 1) ^ sw) << 4) + (g1 & 1) * 8);
-        half4 b0 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((((g0 + 8) >> 1) ^ sw) << 4) + (g0 & 1) * 8);
-        half4 b1 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((((g1 + 8) >> 1) ^ sw) << 4) + (g1 & 1) * 8);
+        const int g0 = 4 * s + h, g1 = g0 + 2;                 // 8-byte granules of the hi part (lo: +8)
+        half4 a0 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((g0 ^ sw) << 3));
+        half4 a1 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((g1 ^ sw) << 3));
+        half4 b0 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g0 + 8) ^ sw) << 3));
+        half4 b1 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g1 + 8) ^ sw) << 3));
         half8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
