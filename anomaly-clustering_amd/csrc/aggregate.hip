@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void agg_pool_kernel(AggParams prm) {
     __syncthreads();
     // adaptive_avg_pool1d(Lk -> pre): window [floor(o*Lk/pre), ceil((o+1)*Lk/pre)), sequential fp32 sum / length
     for (int o = tid; o < prm.pre; o += 256) {
-      const int s = (int)(((long long)o * Lk) / prm.pre);
-      const int e = (int)((((long long)(o + 1)) * Lk + prm.pre - 1) / prm.pre);
+      const int s = (int)(((unsigned)o * (unsigned)Lk) / (unsigned)prm.pre);      // 32-bit: pre*Lk < 2^31 (host check)
+      const int e = (int)(((unsigned)(o + 1) * (unsigned)Lk + (unsigned)prm.pre - 1u) / (unsigned)prm.pre);
       float acc = 0.f;
       for (int i = s; i < e; ++i) acc += U[i];
       const float r = acc / (float)(e - s);
@@ -139,8 +139,84 @@ __global__ __launch_bounds__(256) void agg_pool_kernel(AggParams prm) {
   if (!identity) {
     const int Lv = prm.n_layers * prm.pre;
     for (int t = tid; t < prm.tgt; t += 256) {
-      const int s = (int)(((long long)t * Lv) / prm.tgt);
-      const int e = (int)((((long long)(t + 1)) * Lv + prm.tgt - 1) / prm.tgt);
+      const int s = (int)(((unsigned)t * (unsigned)Lv) / (unsigned)prm.tgt);
+      const int e = (int)(((unsigned)(t + 1) * (unsigned)Lv + (unsigned)prm.tgt - 1u) / (unsigned)prm.tgt);
+      float acc = 0.f;
+      for (int i = s; i < e; ++i) acc += V[i];
+      zrow[t] = acc / (float)(e - s);
+    }
+  }
+}
+
+// ---- pass 2, fast path: every layer is a token map on the reference grid (the ViT case), C % 4 == 0,
+// patch size K in {1, 3}.  The generic kernel above issues one dependent 4-byte global load per LDS
+// element (a run-time trip count keeps hipcc from batching them): ~27 serial L2 round trips per layer,
+// which made the whole kernel latency-bound at 8 % of the HBM roofline.  Here each thread fetches 4
+// channels of all K*K neighbour tokens with K*K independent 16-byte loads in flight, and the LDS image is
+// token-major ([kk][C + 4], 16-byte stores); the pooling loop walks (c, kk) incrementally.
+template <int K>
+__global__ __launch_bounds__(256) void agg_pool_tokens_kernel(AggParams prm) {
+  extern __shared__ float lds[];
+  constexpr int K2 = K * K, PAD = (K - 1) / 2;
+  const int tid = threadIdx.x;
+  const int patch = blockIdx.x, b = blockIdx.y;
+  const int y = patch / prm.W0, x = patch - y * prm.W0;
+  const int C0 = prm.layer[0].C;
+  int maxC = 0;
+  for (int l = 0; l < prm.n_layers; ++l) maxC = max(maxC, prm.layer[l].C);
+  const int Cp = maxC + 4;
+  float* U = lds;                       // [K2][Cp]
+  float* V = lds + K2 * Cp;             // [n_layers*pre] when the final pool is not the identity
+  const bool identity = (prm.n_layers * prm.pre == prm.tgt);
+  float* zrow = prm.Z + ((size_t)b * prm.H0 * prm.W0 + patch) * prm.tgt;
+  (void)C0;
+  for (int l = 0; l < prm.n_layers; ++l) {
+    const AggLayer L = prm.layer[l];
+    const int HW = L.H * L.W, Lk = L.C * K2;
+    const double n = (double)L.C * HW;
+    const double mean_d = L.stats[b * 2] / n;
+    const double var_d = fmax(L.stats[b * 2 + 1] / n - mean_d * mean_d, 0.0);
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)prm.eps));
+    const float* img = L.f + ((size_t)b * (HW + 1) + 1) * L.C;
+    for (int c4 = tid * 4; c4 < L.C; c4 += 1024) {
+      f32x4 ld[K2];
+      bool inb[K2];
+#pragma unroll
+      for (int kk = 0; kk < K2; ++kk) {
+        const int yy = y + kk / K - PAD, xx = x + kk % K - PAD;
+        inb[kk] = (yy >= 0 && yy < L.H && xx >= 0 && xx < L.W);
+        const int yc = min(max(yy, 0), L.H - 1), xc = min(max(xx, 0), L.W - 1);
+        ld[kk] = *reinterpret_cast<const f32x4*>(img + (size_t)(yc * L.W + xc) * L.C + c4);   // unconditional
+      }
+#pragma unroll
+      for (int kk = 0; kk < K2; ++kk) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = inb[kk] ? (ld[kk][j] - mean) * rstd : 0.f;
+        *reinterpret_cast<f32x4*>(U + kk * Cp + c4) = v;
+      }
+    }
+    __syncthreads();
+    for (int o = tid; o < prm.pre; o += 256) {
+      const int s = (int)(((unsigned)o * (unsigned)Lk) / (unsigned)prm.pre);
+      const int e = (int)(((unsigned)(o + 1) * (unsigned)Lk + (unsigned)prm.pre - 1u) / (unsigned)prm.pre);
+      int c = s / K2, kk = s - c * K2;
+      float acc = 0.f;
+      for (int i = s; i < e; ++i) {
+        acc += U[kk * Cp + c];
+        if (++kk == K2) { kk = 0; ++c; }
+      }
+      const float r = acc / (float)(e - s);
+      if (identity) zrow[l * prm.pre + o] = r;
+      else V[l * prm.pre + o] = r;
+    }
+    __syncthreads();
+  }
+  if (!identity) {
+    const int Lv = prm.n_layers * prm.pre;
+    for (int t = tid; t < prm.tgt; t += 256) {
+      const int s = (int)(((unsigned)t * (unsigned)Lv) / (unsigned)prm.tgt);
+      const int e = (int)(((unsigned)(t + 1) * (unsigned)Lv + (unsigned)prm.tgt - 1u) / (unsigned)prm.tgt);
       float acc = 0.f;
       for (int i = s; i < e; ++i) acc += V[i];
       zrow[t] = acc / (float)(e - s);
@@ -183,6 +259,31 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
     if (chunks > 64) chunks = 64;
     hipLaunchKernelGGL(agg_stats_kernel, dim3(chunks, B), dim3(256), 0, stream, feats[l], kind[l], C[l], H[l] * W[l],
                        stats + (size_t)l * B * 2);
+  }
+  AC_REQUIRE((long long)(pre_dim + 1) * maxL < (1LL << 31) && (long long)(tgt_dim + 1) * n_layers * pre_dim < (1LL << 31),
+             "ac_patch_aggregate: pooling index arithmetic would overflow 32 bits");
+  // fast path: all layers are token maps on the reference grid, channels a multiple of 4, K in {1, 3}
+  bool fast = (patchsize == 1 || patchsize == 3);
+  int maxC = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    fast = fast && kind[l] == AC_FEAT_TOKENS && H[l] == H[0] && W[l] == W[0] && C[l] % 4 == 0;
+    maxC = maxC > C[l] ? maxC : C[l];
+  }
+  if (fast) {
+    const bool identity = (n_layers * pre_dim == tgt_dim);
+    size_t flds = ((size_t)patchsize * patchsize * (maxC + 4) + (identity ? 0 : (size_t)n_layers * pre_dim)) * sizeof(float);
+    if (flds <= 160 * 1024) {
+      if (patchsize == 3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_pool_tokens_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        hipLaunchKernelGGL(agg_pool_tokens_kernel<3>, dim3(H[0] * W[0], B), dim3(256), flds, stream, prm);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_pool_tokens_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        hipLaunchKernelGGL(agg_pool_tokens_kernel<1>, dim3(H[0] * W[0], B), dim3(256), flds, stream, prm);
+      }
+      return ac_check_launch("ac_patch_aggregate(tokens)");
+    }
   }
   size_t lds = ((size_t)maxL + (size_t)n_layers * pre_dim) * sizeof(float);
   AC_REQUIRE(lds <= 160 * 1024, "ac_patch_aggregate: C*k*k + layers*pre_dim = %zu floats exceeds LDS", lds / 4);

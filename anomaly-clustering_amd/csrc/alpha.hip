@@ -141,7 +141,14 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   static int v = -1;
   if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
   if (v == 1 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
-  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, 8, part, nparts);
+  // L2 window of the rasterisation (tile rows per group).  In the folded symmetric grid tile (p, c) is
+  // (tm, tn) = (p, 2p + c): a window of P rows x C columns touches P row panels but 2P - 2 + C column
+  // panels, so a flat window (few rows, many columns) re-reads least: 11 KB per tile-stage at 4 x 8 vs
+  // 17 KB at 8 x 4 (FETCH_SIZE confirmed the 8-row window at a 67 % L2 hit rate).
+  static int gm = -1;
+  if (gm < 0) { const char* e = getenv("AC_GROUPM"); gm = e ? atoi(e) : 0; }
+  const int group_m = gm > 0 ? gm : (epi.symmetric ? 4 : 8);
+  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
 }
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {

@@ -49,6 +49,25 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(workload_key, kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of the SAME workload
+    (profiles/*_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes of this
+    script; FETCH_SIZE x2 correction for gfx950).  None when no matching profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("_meta", {}).get("workload_key") != workload_key:
+            continue
+        for k, v in d.items():
+            if kernel_substr in k and "hbm_read_bytes_per_launch" in v and "hbm_write_bytes_per_launch" in v:
+                best = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+    return best
+
+
 def cpu_baseline(n_sample, n_full, category):
     """Time the oracle on a bounded sample: n_sample images embedded, all ordered pairs among them
     for alpha; extrapolate to the category size by per-image and per-pair cost."""
@@ -154,7 +173,8 @@ def main():
         ach = avg_flop / (avg_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_hl_kernel<EpiPairMin>", "achieved": ach,
                 "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP16_MFMA_PEAK_TFLOPS,
-                "traffic": None, "avg_launch_ms": avg_ms, "launches": len(ms),
+                "traffic": pmc_traffic("%s:%s:%d:gpus%d" % (args.category, args.mode, n, world), "EpiPairMin"),
+                "avg_launch_ms": avg_ms, "launches": len(ms),
                 "note": "algorithmic 2*P^2*D FLOP per ordered image pair; the kernel issues 3 fp16 MFMA passes "
                         "per product (split-fp16, fp32-grade), so frac <= 1/3 by construction"}
 

@@ -40,6 +40,13 @@ def main():
         fl = N * N * 2.0 * 784 * 784 * 4096
         print("N=%d symmetric %.2f ms (%.0f TF algorithmic)  general %.2f ms (%.0f TF)"
               % (N, ms[1], fl / ms[1] / 1e9, ms[3], fl / ms[3] / 1e9))
+    elif what == "agg":
+        B = int(sys.argv[2])
+        f10 = torch.randn(B, 785, 768, device=dev)
+        f11 = torch.randn(B, 785, 768, device=dev)
+        t = timeit(lambda: acnative.patch_aggregate([f10, f11], 3, 2048, 4096), 5)
+        print("B=%d aggregate %.3f ms  (%.1f us/img, %.2f TB/s algorithmic at 17.7 MB/img)"
+              % (B, t * 1e3, t * 1e6 / B, B * 17.7e6 / t / 1e12))
     elif what == "vit":
         B = int(sys.argv[2])
         import patchcore.vision_transformer as vits
