@@ -13,7 +13,7 @@ or dataset is reachable offline).  With --gpus G the same category is sharded ov
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (gemm_hl_kernel<EpiPairMin>, the fused all-pairs
+  roofline     - the dominant kernel (gemm2::kernel<EpiPairMin, true>, the fused all-pairs
                  min-distance MFMA GEMM): algorithmic FLOPs per launch / average launch
                  duration measured with events on the launch stream inside the timed region.
   cpu_baseline - the CPU oracle (a port of the reference's arithmetic) timed on this host on a
@@ -171,12 +171,15 @@ def main():
         avg_ms = sum(ms) / len(ms)
         avg_flop = sum(flops) / len(flops)
         ach = avg_flop / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_hl_kernel<EpiPairMin>", "achieved": ach,
+        roof = {"bound": "mfma", "kernel": "gemm2::kernel<EpiPairMin, true>", "achieved": ach,
                 "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP16_MFMA_PEAK_TFLOPS,
                 "traffic": pmc_traffic("%s:%s:%d:gpus%d" % (args.category, args.mode, n, world), "EpiPairMin"),
                 "avg_launch_ms": avg_ms, "launches": len(ms),
-                "note": "algorithmic 2*P^2*D FLOP per ordered image pair; the kernel issues 3 fp16 MFMA passes "
-                        "per product (split-fp16, fp32-grade), so frac <= 1/3 by construction"}
+                "note": "achieved = algorithmic 2*P^2*D FLOP per ORDERED image pair / launch time. The kernel issues 3 "
+                        "fp16 MFMA passes per product (split-fp16, fp32-grade) and, when keys == queries, computes "
+                        "only the upper triangle of tiles (each reduced both ways), so issued MFMA work = 1.5x the "
+                        "algorithmic FLOPs on one GPU and frac <= 2/3 by construction; traffic = L2-miss (fabric) "
+                        "bytes per launch from the committed PMC passes of this workload"}
 
     # per-stage breakdown (one extra, untimed-for-the-metric step)
     stages = {}
