@@ -309,43 +309,49 @@ extern "C" int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, do
 }
 
 // --------------------------------------------------------- weighted average
-// X[i][d] = sum_p alpha[i][p] * Z[i][p][d].  HBM-bound (reads Z once): block = (image, 1024
-// columns, one of S patch slices), each thread owns 4 consecutive columns (16-byte loads,
-// a wave reads 1 KB contiguous per patch row); slices combine through fp32 atomics only when
-// S > 1 (small N), otherwise plain stores.
+// X[i][d] = sum_p alpha[i][p] * Z[i][p][d].  HBM-bound (reads Z once).  Block = (image, 256 columns):
+// 64 threads x 4 columns wide (a wave-row reads 1 KB contiguous of one patch row) and 4 patch
+// phases deep; every thread keeps 4 independent 16-byte loads in flight (patches p, p+4, p+8, p+12 of
+// its phase), the phases meet in LDS in a fixed order.  No atomics: X is bitwise reproducible.
 __global__ __launch_bounds__(256) void weighted_avg_kernel(const float* __restrict__ alpha, const float* __restrict__ Z,
-                                                           int P, int D, int slices, float* __restrict__ X) {
-  const int img = blockIdx.z, slice = blockIdx.y;
-  const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (d >= D) return;
-  const int per = (P + slices - 1) / slices;
-  const int p0 = slice * per, p1 = min(P, p0 + per);
+                                                           int P, int D, float* __restrict__ X) {
+  __shared__ f32x4 red[4][64];
+  const int img = blockIdx.y;
+  const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  const int d = (blockIdx.x * 64 + lane) * 4;
+  const bool live = d < D;
   const float* a = alpha + (size_t)img * P;
-  const float* z = Z + ((size_t)img * P) * D + d;
-  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-  int p = p0;
-  for (; p + 1 < p1; p += 2) {
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(z + (size_t)p * D);
-    f32x4 v1 = *reinterpret_cast<const f32x4*>(z + (size_t)(p + 1) * D);
-    float a0 = a[p], a1 = a[p + 1];
+  const float* z = Z + ((size_t)img * P) * D + (live ? d : 0);
+  f32x4 acc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { acc0[j] = fmaf(a0, v0[j], acc0[j]); acc1[j] = fmaf(a1, v1[j], acc1[j]); }
-  }
-  if (p < p1) {
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(z + (size_t)p * D);
-    float a0 = a[p];
+  for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int p = phase;
+  for (; p + 12 < P; p += 16) {
+    f32x4 v[4];
+    float w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc0[j] = fmaf(a0, v0[j], acc0[j]);
+    for (int u = 0; u < 4; ++u) { v[u] = *reinterpret_cast<const f32x4*>(z + (size_t)(p + 4 * u) * D); w[u] = a[p + 4 * u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[u][j] = fmaf(w[u], v[u][j], acc[u][j]);
   }
-  float* x = X + (size_t)img * D + d;
-  if (slices == 1) {
+  for (int u = 0; p < P; p += 4, ++u) {                  // tail: at most 3 more patches of this phase
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + (size_t)p * D);
+    const float w = a[p];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[u & 3][j] = fmaf(w, v[j], acc[u & 3][j]);
+  }
+  f32x4 s;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
+  red[phase][lane] = s;
+  __syncthreads();
+  if (phase == 0 && live) {
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = acc0[j] + acc1[j];
-    *reinterpret_cast<f32x4*>(x) = o;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(x + j, acc0[j] + acc1[j]);
+    for (int j = 0; j < 4; ++j) o[j] = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+    *reinterpret_cast<f32x4*>(X + (size_t)img * D + d) = o;
   }
 }
 
@@ -355,13 +361,7 @@ extern "C" int ac_weighted_avg(const float* alpha, const float* Z, int64_t N, in
   AC_REQUIRE(P > 0 && D > 0 && D % 4 == 0, "ac_weighted_avg: bad shape P=%d D=%d (D %% 4 == 0)", P, D);
   AC_REQUIRE(N >= 0 && N <= 65535, "ac_weighted_avg: N=%lld out of range (<= 65535 per call)", (long long)N);
   if (N == 0) return AC_OK;
-  int col_blocks = (D / 4 + 255) / 256;
-  // enough blocks to cover the chip (256 CUs x ~8) without atomics when N is already large
-  int slices = 1;
-  while ((int64_t)N * col_blocks * slices < 2048 && slices * 2 <= 16 && P / (slices * 2) >= 16) slices *= 2;
-  if (slices > 1) (void)hipMemsetAsync(X, 0, (size_t)N * D * 4, stream);
-  hipLaunchKernelGGL(weighted_avg_kernel, dim3(col_blocks, slices, (unsigned)N), dim3(256), 0, stream, alpha, Z, P, D,
-                     slices, X);
+  hipLaunchKernelGGL(weighted_avg_kernel, dim3((D / 4 + 63) / 64, (unsigned)N), dim3(256), 0, stream, alpha, Z, P, D, X);
   return ac_check_launch("weighted_avg");
 }
 

@@ -120,18 +120,22 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
         train_images = _stack_images(_dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset))
     out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
                        train_images=train_images, train_ratio=train_ratio, want_pdist=False)
-    matrix_alpha, X = out["alpha"], out["X"]
-
-    data_matrix = (matrix_alpha.cpu(), X)
+    # `tau` may be a list (a sweep): embeddings and patch distances were computed once; one artefact per tau
+    taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
     rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
-    if rank0:
-        folder = artefact_dir(save_path, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension,
-                              tau, train_ratio)
-        os.makedirs(folder, exist_ok=True)
-        torch.save(data_matrix, folder + "/matrix_alpha_X_" + category + "_" + supervised + ".pickle")
-        if info_dir is not None:
-            os.makedirs(info_dir, exist_ok=True)
-            torch.save(info, os.path.join(info_dir, "info_" + category + ".pickle"))
+    data_matrix = None
+    for tv in taus:
+        res = out["by_tau"][float(tv)]
+        this = (res["alpha"].cpu(), res["X"])
+        data_matrix = data_matrix or this
+        if rank0:
+            folder = artefact_dir(save_path, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension,
+                                  tv, train_ratio)
+            os.makedirs(folder, exist_ok=True)
+            torch.save(this, folder + "/matrix_alpha_X_" + category + "_" + supervised + ".pickle")
+    if rank0 and info_dir is not None:
+        os.makedirs(info_dir, exist_ok=True)
+        torch.save(info, os.path.join(info_dir, "info_" + category + ".pickle"))
     print("{:-^80}".format(category + ' end'))
     return data_matrix
 
@@ -146,6 +150,9 @@ def build_parser():
     parser.add_argument('--output_dir', default="outputs", help='Path where to save segmentations')
     parser.add_argument("--patchsize", type=int, default=3, help="Patch Size.")
     parser.add_argument("--tau", type=float, default=1, help="Tau.")
+    parser.add_argument("--tau_list", nargs="*", type=float, default=None,
+                        help="Sweep: several tau values from ONE embedding + patch-distance pass per category "
+                             "(the reference's test.py reads 0 0.2 0.4 0.6 0.8 1 1.5 2 2.5 3 4 8 10 12 14 18 20).")
     parser.add_argument("--train_ratio", type=float, default=1, help="The ratio of train data.")
     parser.add_argument('--supervised', default='unsupervised', type=str,
                         help="unsupervised | supervised | average | both")
@@ -172,7 +179,8 @@ def main(argv=None):
                 path=args.path, category=category, pretrain_embed_dimension=args.pretrain_embed_dimension,
                 target_embed_dimension=args.target_embed_dimension, backbone_names=args.backbone_names,
                 layers_to_extract_from=args.layers_to_extract_from, patchsize=args.patchsize, save_path=save_path,
-                tau=args.tau, train_ratio=args.train_ratio, supervised=supervised, dataset=args.dataset,
+                tau=(args.tau_list if args.tau_list else args.tau), train_ratio=args.train_ratio,
+                supervised=supervised, dataset=args.dataset,
                 info_dir=args.output_dir + "/" + args.dataset + "/info", backbone=backbone,
                 batch_size=args.batch_size)
     return results

@@ -103,6 +103,8 @@ def select_bank(n_train, n_test, train_ratio, seed=0):
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
+    `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
+    own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
     Returns dict(alpha fp32 [N, 1, P] on device, X float32 ndarray [N, D], X_dev, pdist (rank 0), bounds)."""
     rank, world = _world(group)
     n = images.shape[0]
@@ -130,7 +132,6 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         bank_loc = ops.embed(train_images[sel[blo:bhi]])
         bank = all_gather_rows(bank_loc, [b - a for a, b in bb], group)
         w_loc = ops.pair_min_dist(Z_loc, bank, 1, 0)
-        alpha_loc = ops.alpha_softmax(w_loc, tau, k)
     elif supervised == "unsupervised":
         Z_all = all_gather_rows(Z_loc, counts, group)
         P = Z_all.shape[1]
@@ -143,23 +144,34 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
             w_loc = ops.pair_reduce(minbuf[:, lo * P: hi * P].contiguous(), P, 0, lo)
         else:
             w_loc = ops.pair_min_dist(Z_loc, Z_all, 0, lo)
-        alpha_loc = ops.alpha_softmax(w_loc, tau, k)
     else:                                                              # "average" (main.py:290-291)
-        alpha_loc = torch.ones(Z_loc.shape[0], Z_loc.shape[1], device=Z_loc.device) / Z_loc.shape[1]
-    mark("alpha", t0)
+        w_loc = None
+    mark("pair_min_dist", t0)
 
-    t0 = time.perf_counter()
-    alpha_f32 = alpha_loc.float().contiguous()                         # main.py:294 `.float()`
-    X_loc = ops.weighted_avg(alpha_f32, Z_loc)
-    X = all_gather_rows(X_loc, counts, group)
-    alpha = all_gather_rows(alpha_f32, counts, group).unsqueeze(1)
-    mark("weighted_avg_gather", t0)
-
-    out = {"alpha": alpha, "X_dev": X, "bounds": bounds}
-    t0 = time.perf_counter()
-    if want_pdist and rank == 0:
-        out["pdist"] = ops.pdist(X)
-    mark("pdist", t0)
-    if want_host:
-        out["X"] = np.array(X.cpu().numpy(), dtype=np.float32, copy=True)      # main.py:294-296 `.cpu()` + np.array
+    # w does not depend on tau (and Z not on the mode): a tau sweep - the reference re-runs everything per
+    # tau (examples/main.py:346-366, README "tau_list") - only repeats the cheap tail below.
+    taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
+    by_tau = {}
+    for tv in taus:
+        t0 = time.perf_counter()
+        if w_loc is None:
+            alpha_loc = torch.ones(Z_loc.shape[0], Z_loc.shape[1], device=Z_loc.device) / Z_loc.shape[1]
+        else:
+            alpha_loc = ops.alpha_softmax(w_loc, tv, k)
+        alpha_f32 = alpha_loc.float().contiguous()                     # main.py:294 `.float()`
+        X_loc = ops.weighted_avg(alpha_f32, Z_loc)
+        X = all_gather_rows(X_loc, counts, group)
+        alpha = all_gather_rows(alpha_f32, counts, group).unsqueeze(1)
+        mark("alpha_softmax_weighted_avg_gather", t0)
+        res = {"alpha": alpha, "X_dev": X}
+        t0 = time.perf_counter()
+        if want_pdist and rank == 0:
+            res["pdist"] = ops.pdist(X)
+        mark("pdist", t0)
+        if want_host:
+            res["X"] = np.array(X.cpu().numpy(), dtype=np.float32, copy=True)  # main.py:294-296 `.cpu()` + np.array
+        by_tau[float(tv)] = res
+    out = dict(by_tau[float(taus[0])])
+    out["bounds"] = bounds
+    out["by_tau"] = by_tau
     return out

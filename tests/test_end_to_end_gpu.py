@@ -106,3 +106,26 @@ def test_main_then_test_scripts_match_oracle(tmp_path, dev, small_model, mode, m
     print(mode, "NMI/ARI/F1 ours %.4f %.4f %.4f  oracle %.4f %.4f %.4f" % (NMI, ARI, F1, rN, rA, rF))
     assert abs(NMI - rN) <= 1e-3 and abs(ARI - rA) <= 1e-3 and abs(F1 - rF) <= 1e-3
     assert np.array_equal(label, rl)
+
+
+def test_tau_sweep_reuses_one_pass(dev, small_model):
+    """run_category with a list of taus == separate runs, one embedding + distance pass."""
+    import patchcore.common as common
+    import patchcore.sampler
+    from patchcore.patchcore import AnomalyClusteringCore
+    from patchcore.pipeline import HipOps, run_category
+    from patchcore.datasets import synthetic
+    core = AnomalyClusteringCore(dev)
+    core.load(backbone=small_model, layers_to_extract_from=["blocks.2", "blocks.3"], device=dev,
+              input_shape=(3, 224, 224), pretrain_embed_dimension=2048, target_embed_dimension=4096, patchsize=3,
+              featuresampler=patchcore.sampler.IdentitySampler(), nn_method=common.FaissNN(False, 4))
+    images = synthetic.make_images("grid", ["good", "bent", "bent", "glue", "good"]).to(dev)
+    ops = HipOps(core, batch_size=8)
+    sweep = run_category(ops, images, "unsupervised", tau=[0, 0.5, 2.0])
+    assert sorted(sweep["by_tau"]) == [0.0, 0.5, 2.0]
+    for tv in (0, 0.5, 2.0):
+        single = run_category(ops, images, "unsupervised", tau=tv)
+        assert torch.equal(single["alpha"], sweep["by_tau"][float(tv)]["alpha"])
+        assert np.array_equal(single["X"], sweep["by_tau"][float(tv)]["X"])
+    a0 = sweep["by_tau"][0.0]["alpha"].squeeze(1)
+    assert torch.all((a0 > 0).sum(1) >= 1) and torch.allclose(a0.sum(1), torch.ones(5, device=dev))
