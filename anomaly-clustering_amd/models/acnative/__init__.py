@@ -337,6 +337,8 @@ def pair_reduce(minbuf, P, reduce, self_first=0):
     nk, cols = minbuf.shape
     nq = cols // P
     w = torch.empty((nq, P), dtype=torch.float32, device=minbuf.device)
+    if nq == 0:                      # a rank with an empty image shard
+        return w
     _check(lib().ac_pair_reduce(p, nk, nq, P, reduce, self_first, w.data_ptr(), _stream()))
     return w
 
@@ -345,15 +347,19 @@ def alpha_softmax(w, tau, k=1.0):
     p = _dev(w, torch.float32, "w")
     N, P = w.shape
     a = torch.empty((N, P), dtype=torch.float64, device=w.device)
+    if N == 0:
+        return a
     _check(lib().ac_alpha_softmax(p, N, P, float(tau), float(k), a.data_ptr(), _stream()))
     return a
 
 
 def weighted_avg(alpha, Z):
     """alpha fp32 [N, P] (or [N,1,P]), Z fp32 [N, P, D] -> X fp32 [N, D]."""
+    N, P, D = Z.shape
+    if N == 0:                           # a rank with an empty image shard
+        return torch.empty((0, D), dtype=torch.float32, device=Z.device)
     alpha = alpha.reshape(alpha.shape[0], -1).contiguous()
     pa, pz = _dev(alpha, torch.float32, "alpha"), _dev(Z, torch.float32, "Z")
-    N, P, D = Z.shape
     if alpha.shape != (N, P):
         raise ValueError("alpha %s does not match Z %s" % (tuple(alpha.shape), tuple(Z.shape)))
     X = torch.empty((N, D), dtype=torch.float32, device=Z.device)

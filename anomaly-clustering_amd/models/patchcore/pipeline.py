@@ -40,11 +40,21 @@ class HipOps:
         self.acnative = acnative
         self.core = core
         self.batch_size = batch_size
+        self._zshape = None
 
     def embed(self, images):
-        return self.core.embed_device(images, batch_size=self.batch_size)
+        if images.shape[0] == 0:                     # empty shard (fewer images than ranks)
+            if self._zshape is None:
+                probe = torch.ones((1,) + tuple(self.core.input_shape), device=self.core.device)
+                self._zshape = tuple(self.core.embed_device(probe, batch_size=1).shape[1:])
+            return torch.empty((0,) + self._zshape, dtype=torch.float32, device=self.core.device)
+        Z = self.core.embed_device(images, batch_size=self.batch_size)
+        self._zshape = tuple(Z.shape[1:])
+        return Z
 
     def pair_min_dist(self, Zq, Zk, reduce, self_offset):
+        if Zq.shape[0] == 0:
+            return torch.empty((0, Zq.shape[1]), dtype=torch.float32, device=Zq.device)
         return self.acnative.pair_min_dist_staged(Zq, Zk, reduce, self_offset)
 
     def pair_min_sq_part(self, Z, part, nparts):

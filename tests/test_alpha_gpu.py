@@ -206,3 +206,20 @@ def test_errors_are_loud(dev):
         acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         acnative.pair_min_dist(torch.zeros(2, 8, 64), torch.zeros(2, 8, 64), 0)
+
+
+def test_degenerate_category_sizes(dev):
+    """N = 1: the unsupervised mean over "the other images" is empty - NaN, as torch.mean of an empty tensor
+    in the reference (utils.py:227); N = 2: each image's only key image is the other one."""
+    import acnative
+    from oracle import alpha as oa
+    Zs, _ = clustered_embeddings(2, 50, 64, 2, salt=91)
+    Z = torch.from_numpy(Zs).to(dev)
+    w1 = acnative.pair_min_dist(Z[:1].contiguous(), Z[:1].contiguous(), acnative.REDUCE_MEAN_OTHERS)
+    assert torch.isnan(w1).all()          # the reference itself fails here (mean over dim 1 of an empty 1-D tensor)
+    with pytest.raises((ValueError, IndexError, RuntimeError)):
+        oa.weights_unsupervised(torch.from_numpy(Zs[:1]))
+    w2 = acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS).cpu().numpy()
+    assert _w_close(w2, oa.weights_unsupervised(torch.from_numpy(Zs)).numpy())
+    ws = acnative.pair_min_dist(Z[:1].contiguous(), Z[1:].contiguous(), acnative.REDUCE_MIN_ALL).cpu().numpy()
+    assert _w_close(ws, oa.weights_supervised(torch.from_numpy(Zs[:1]), torch.from_numpy(Zs[1:])).numpy())

@@ -71,3 +71,31 @@ def test_two_ranks_on_one_gpu_match_one_rank(dev, mode):
             # batches of different size take different tile paths in the ViT GEMMs: fp32-level, not bitwise
             np.testing.assert_allclose(a, ref["alpha"].cpu().numpy(), rtol=2e-4, atol=1e-8)
             np.testing.assert_allclose(X, ref["X"], rtol=0, atol=2e-5)
+
+
+def _worker_small(rank, world, init_file, out_dir):
+    sys.path[:0] = [ROOT, MODELS]
+    from patchcore.pipeline import HipOps, run_category
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    core = _build(dev)
+    test, _ = _images()
+    out = run_category(HipOps(core, batch_size=4), test[:2].to(dev), "unsupervised", tau=1.0)   # 2 images, 3 ranks
+    np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_more_ranks_than_images(dev):
+    """N = 2 images over 3 ranks: one rank owns an empty shard and still takes part in every collective."""
+    from patchcore.pipeline import HipOps, run_category
+    core = _build(dev)
+    test, _ = _images()
+    ref = run_category(HipOps(core, batch_size=4), test[:2].to(dev), "unsupervised", tau=1.0)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_small, args=(3, os.path.join(d, "rdzv"), d), nprocs=3, join=True)
+        for r in range(3):
+            a = np.load(os.path.join(d, "alpha_%d.npy" % r))
+            assert a.shape == (2, 1, 784)
+            np.testing.assert_allclose(a, ref["alpha"].cpu().numpy(), rtol=2e-4, atol=1e-8)
