@@ -199,6 +199,18 @@ def test_weighted_avg_and_pdist_vs_oracle(dev):
     np.testing.assert_allclose(d, oc.pdist(Xr), rtol=1e-12, atol=0)
 
 
+def test_pdist_both_kernels(dev):
+    """N <= 1024 takes the wave-per-2x2-pairs kernel, larger N the LDS-tiled one; odd N, D not a multiple of 64."""
+    import acnative
+    from oracle import cluster as oc
+    for n, d in ((2, 8), (83, 4096), (167, 100), (1100, 72)):
+        Xr = gaussish_tensor((n, d), salt=300 + n)
+        got = acnative.pdist(torch.from_numpy(Xr).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(got, oc.pdist(Xr), rtol=1e-12, atol=0, err_msg=str((n, d)))
+    again = acnative.pdist(torch.from_numpy(Xr).to(dev)).cpu().numpy()
+    assert np.array_equal(got, again)                 # fixed summation order: bitwise reproducible
+
+
 def test_errors_are_loud(dev):
     import acnative
     Z = torch.zeros(2, 8, 48, device=dev)      # D not a multiple of 32
