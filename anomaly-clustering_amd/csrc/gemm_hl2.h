@@ -42,6 +42,12 @@ constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
 constexpr int LDS_BYTES = NSTAGE * STAGE;                                           // 144 KB
 constexpr int FLUSH_STAGES = 16;
 
+// Timing-only diagnostic builds (results are wrong): -DAC_ABLATE=1 no DMA issue in the loop, 2 no
+// fragment reads after stage 0, 4 no MFMAs (combinable).  0 in every shipped build.
+#ifndef AC_ABLATE
+#define AC_ABLATE 0
+#endif
+
 __device__ inline int tile_off(int row, int lc) { return row * 128 + ((lc ^ ((row >> 1) & 7)) << 4); }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -144,24 +150,27 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     wait_one_stage_in_flight(nk > 1);
     barrier();                                      // #0: stage 0 visible to everyone
     if (groupB) barrier();
+    half8 ah[4], al[4], bh[4], bl[4];
     for (int kt = 0; kt < nk; ++kt) {
       // ---------------- P1(kt)
       const uint8_t* cur = smem + (kt % NSTAGE) * STAGE;
-      half8 ah[4], al[4], bh[4], bl[4];
+      if (!(AC_ABLATE & 2) || kt == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ah[t] = *reinterpret_cast<const half8*>(cur + a_off[t][0]);
-        al[t] = *reinterpret_cast<const half8*>(cur + a_off[t][1]);
-        bh[t] = *reinterpret_cast<const half8*>(cur + b_off[t][0]);
-        bl[t] = *reinterpret_cast<const half8*>(cur + b_off[t][1]);
+        for (int t = 0; t < 4; ++t) {
+          ah[t] = *reinterpret_cast<const half8*>(cur + a_off[t][0]);
+          al[t] = *reinterpret_cast<const half8*>(cur + a_off[t][1]);
+          bh[t] = *reinterpret_cast<const half8*>(cur + b_off[t][0]);
+          bl[t] = *reinterpret_cast<const half8*>(cur + b_off[t][1]);
+        }
       }
-      if (kt + 2 < nk) issue(kt + 2);
+      if (kt + 2 < nk && !(AC_ABLATE & 1)) issue(kt + 2);
       if (groupB) wait_one_stage_in_flight(kt + 2 < nk);      // own share of stage kt+1 landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- P2(kt)
       __builtin_amdgcn_s_setprio(1);
+      if (!(AC_ABLATE & 4))
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

@@ -12,7 +12,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libac_hip.so")
+LIB_PATH = os.environ.get("AC_LIB") or os.path.join(_HERE, "libac_hip.so")   # AC_LIB: diagnostic builds only
 
 REDUCE_MEAN_OTHERS = 0
 REDUCE_MIN_ALL = 1
