@@ -2,7 +2,7 @@
 // fp64 softmax, weighted-average embedding, condensed pdist.
 // Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
 // scipy pdist under examples/test.py:193-195.
-#include "gemm_hl2.h"
+#include "gemm_hl3.h"
 #include <stdlib.h>
 
 // ------------------------------------------------------------------ packing
@@ -141,6 +141,8 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   static int v = -1;
   if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
   if (v == 1 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
+  // experimental 256x256 kernel: general (non-symmetric) problems only, single accumulation (timing studies)
+  if (v == 5 && nparts == 1 && !epi.symmetric) return gemm3::launch(A, B, M, N, K, epi, stream, 4);
   // L2 window of the rasterisation (tile rows per group).  In the folded symmetric grid tile (p, c) is
   // (tm, tn) = (p, 2p + c): a window of P rows x C columns touches P row panels but 2P - 2 + C column
   // panels, so a flat window (few rows, many columns) re-reads least: 11 KB per tile-stage at 4 x 8 vs

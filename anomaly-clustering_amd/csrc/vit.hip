@@ -8,7 +8,7 @@
 // everything that feeds an MFMA (LN output, q/k/v, attention output, GELU output) is written
 // directly in hl32 form by the producing kernel's epilogue - same bytes as fp32, no
 // conversion pass.
-#include "gemm_hl2.h"
+#include "gemm_hl3.h"
 #include <stdlib.h>
 
 constexpr int HD = 64;          // head dim (all DINO ViTs)
@@ -22,6 +22,7 @@ static int gemm_version() {
 template <class Epi>
 static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
   if (gemm_version() == 1) return gemm::launch(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
   return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream);
 }
 
