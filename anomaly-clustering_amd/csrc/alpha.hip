@@ -3,6 +3,7 @@
 // Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
 // scipy pdist under examples/test.py:193-195.
 #include "gemm_hl3.h"
+#include "gemm_hl4.h"
 #include <stdlib.h>
 
 // ------------------------------------------------------------------ packing
@@ -150,6 +151,8 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   static int gm = -1;
   if (gm < 0) { const char* e = getenv("AC_GROUPM"); gm = e ? atoi(e) : 0; }
   const int group_m = gm > 0 ? gm : (epi.symmetric ? 4 : 8);
+  // experimental loader-specialised kernel: single accumulation (timing studies)
+  if (v == 6) return gemm4::launch<EpiPairMin>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
 }
 

@@ -9,6 +9,7 @@
 // directly in hl32 form by the producing kernel's epilogue - same bytes as fp32, no
 // conversion pass.
 #include "gemm_hl3.h"
+#include "gemm_hl4.h"
 #include <stdlib.h>
 
 constexpr int HD = 64;          // head dim (all DINO ViTs)
@@ -23,6 +24,7 @@ template <class Epi>
 static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
   if (gemm_version() == 1) return gemm::launch(A, B, M, N, K, epi, stream);
   if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 6) return gemm4::launch<Epi>(A, B, M, N, K, epi, stream);
   return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream);
 }
 
