@@ -152,7 +152,8 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   if (gm < 0) { const char* e = getenv("AC_GROUPM"); gm = e ? atoi(e) : 0; }
   const int group_m = gm > 0 ? gm : (epi.symmetric ? 4 : 8);
   // experimental loader-specialised kernel: single accumulation (timing studies)
-  if (v == 6) return gemm4::launch<EpiPairMin>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 6) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 7) return gemm4::launch<EpiPairMin, 1>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
 }
 

@@ -18,6 +18,7 @@
 // distinct slots (MI355X LDS banking: 4 x 16-lane groups, 64 banks).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace gemm {
 
@@ -82,6 +83,21 @@ using Frag = FragT<32>;
 // emit full 128-byte lines with 16-byte stores (gemm_hl2.h uses it; the 64 KB kernel cannot).
 template <class Epi> struct EpiTraits { static constexpr bool kSymmetric = false; static constexpr bool kStaged = false; };
 constexpr int EPI_PITCH = 68;   // floats per staged row: 16-byte aligned, conflict-free for ds_read_b128
+
+// Swapped orientation (gemm_hl2.h only; an epilogue opts in with `static constexpr bool kSwap = true`
+// and a `swapped(frag, m_wave, n_wave, lane)` method).  The MFMA gets the B fragment as its first
+// operand, so the accumulator tile is C^T: lane l then holds, of tile (mi, ni), row mi*16 + (l&15) and
+// FOUR CONSECUTIVE columns - and because the kernel also permutes which B row feeds which MFMA slot,
+// tiles 2p and 2p+1 together give the lane EIGHT consecutive columns: 32p + 8(l>>4) + 0..7 =
+// acc[mi][2p][0..3], acc[mi][2p+1][0..3].  A row-major epilogue needs no LDS transpose: fp32 output is two
+// 16-byte stores per (mi, p), hl32 output one 16-byte store per plane, and a wave-instruction covers 16
+// rows x 64 (hl32) or 128 (fp32) contiguous bytes.
+template <class E, class = void> struct HasSwap : std::false_type {};
+template <class E> struct HasSwap<E, std::void_t<decltype(E::kSwap)>> : std::bool_constant<E::kSwap> {};
+struct SwapFrag {
+  __device__ static int row(int mi, int lane) { return mi * 16 + (lane & 15); }
+  __device__ static int col8(int p, int lane) { return 32 * p + 8 * (lane >> 4); }
+};
 
 // Epi must provide:  __device__ void operator()(const Frag&, int m_wave, int n_wave, int lane) const
 //   m_wave / n_wave = first row / column of this wave's 64x64 sub-tile.

@@ -48,6 +48,20 @@ constexpr int FLUSH_STAGES = 16;
 #define AC_ABLATE 0
 #endif
 
+// Diagnostic build -DAC_TILE_TIMING: every workgroup records 100 MHz timestamps (entry, first stage
+// visible, k loop done, epilogue stores done) into a per-TU buffer; the `stagger` argument then carries
+// the launch slot instead.  Read back with ac_debug_tile_times (vit.hip).  Never defined in shipped builds.
+#ifdef AC_TILE_TIMING
+constexpr int TT_SLOTS = 8, TT_BLOCKS = 8192;
+static __device__ unsigned long long ac_tile_times[TT_SLOTS * TT_BLOCKS * 4];
+inline int& tt_counter() { static int c = 0; return c; }
+#define AC_STAMP(k)                                                                                   \
+  if (tid == 0 && blockIdx.x < gemm2::TT_BLOCKS)                                                   \
+    gemm2::ac_tile_times[((size_t)(stagger & 7) * gemm2::TT_BLOCKS + blockIdx.x) * 4 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define AC_STAMP(k)
+#endif
+
 __device__ inline int tile_off(int row, int lc) { return row * 128 + ((lc ^ ((row >> 1) & 7)) << 4); }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -79,12 +93,25 @@ __device__ inline bool tile_of(int id, int tiles_m, int tiles_n, int group_m, in
 template <class Epi, bool FLUSH>
 __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
-                                                     int id_lo, int id_hi, Epi epi) {
+                                                     int id_lo, int id_hi, int stagger, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const bool groupB = wave >= 4;
+  constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
+  // De-synchronise the CUs.  Equal tiles keep all 256 CUs in lockstep, so every round ends in one burst
+  // of epilogue traffic (256 KB per CU at once) during which no MFMA runs anywhere.  The first block of
+  // each CU (blockIdx < 256; blocks go round-robin over the 8 XCDs, so (blockIdx >> 3) & 31 is the CU
+  // slot within its XCD) starts `stagger` x slot x 64 cycles late; the offsets persist from tile to tile
+  // and the bursts turn into a steady background stream.
+#ifndef AC_TILE_TIMING
+  if (stagger > 0 && blockIdx.x < 256) {
+    const int n = stagger * ((blockIdx.x >> 3) & 31);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
+  AC_STAMP(0);
   const size_t ld = (size_t)K * 4;
   const int nk = K / BK;
 
@@ -112,7 +139,10 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       const bool isA = j < 4;
       const int row = (isA ? g : g - 32) * 8 + (lane >> 3);
       const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      const uint8_t* base = isA ? A + (size_t)min(tm * BM + row, M - 1) * ld : B + (size_t)min(tn * BN + row, N - 1) * ld;
+      // swapped orientation: LDS row r of the B tile holds global row perm(r) (bits 4|3:2 -> 2|4:3 within
+      // each group of 32), which makes a lane's two tiles of a pair cover 8 consecutive columns
+      const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
+      const uint8_t* base = isA ? A + (size_t)min(tm * BM + row, M - 1) * ld : B + (size_t)min(tn * BN + brow, N - 1) * ld;
       src[j] = base + lc * 16;
     }
     return true;
@@ -149,6 +179,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 
     wait_one_stage_in_flight(nk > 1);
     barrier();                                      // #0: stage 0 visible to everyone
+    AC_STAMP(1);
     if (groupB) barrier();
     half8 ah[4], al[4], bh[4], bl[4];
     for (int kt = 0; kt < nk; ++kt) {
@@ -175,9 +206,15 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-          f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], f.acc[mi][ni], 0, 0, 0);
-          f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
-          f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
+          if constexpr (SWAP) {
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah[mi], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al[mi], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah[mi], f.acc[mi][ni], 0, 0, 0);
+          } else {
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
+            f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_s_setprio(0);
       // Two-level accumulation (see gemm_hl.h): flush the MFMA accumulator every 512 k-terms.
@@ -194,6 +231,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       barrier();
     }
     if (!groupB) barrier();                         // both groups are past their last ring read
+    AC_STAMP(2);
     if (FLUSH) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -208,11 +246,13 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     int next = id + gridDim.x;
     bool has_next = false;
     while (next < id_hi && !(has_next = setup(next))) next += gridDim.x;
-    constexpr bool kUsesLds = EpiTraits<Epi>::kStaged || EpiTraits<Epi>::kSymmetric;
+    constexpr bool kUsesLds = !SWAP && (EpiTraits<Epi>::kStaged || EpiTraits<Epi>::kSymmetric);
     if (has_next && !kUsesLds) { issue(0); if (nk > 1) issue(1); }
 
     const int m_wave = m0 + wm * 64, n_wave = n0 + wn * 64;
-    if constexpr (EpiTraits<Epi>::kStaged) {
+    if constexpr (SWAP) {
+      epi.swapped(f, m_wave, n_wave, lane);
+    } else if constexpr (EpiTraits<Epi>::kStaged) {
       float* t = reinterpret_cast<float*>(smem) + wave * (64 * gemm::EPI_PITCH);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -238,8 +278,13 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     } else {
       epi(f, m_wave, n_wave, lane);
     }
+#ifdef AC_TILE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    AC_STAMP(3);
+#endif
     if (!has_next) break;
-    if (kUsesLds) {                                 // the epilogue used the ring: everyone must be out of it
+    if (kUsesLds) {                                // the epilogue used the ring: everyone must be out of it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       barrier();
       issue(0);
@@ -255,7 +300,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 // all-pairs problem over several GPUs.
 template <class Epi, bool FLUSH = false>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                  int group_m = 8, int part = 0, int nparts = 1) {
+                  int group_m = 8, int part = 0, int nparts = 1, int stagger = 0) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl2: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl2: bad part %d/%d", part, nparts);
@@ -294,9 +339,13 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   static int persist = -1;
   if (persist < 0) { const char* e = getenv("AC_PERSIST"); persist = (e && e[0] == '1') ? 1 : 0; }
   long long grid = (persist && hi - lo > n_cu) ? n_cu : hi - lo;
+  int stagger_arg = (hi - lo > 2 * n_cu && !persist) ? stagger : 0;
+#ifdef AC_TILE_TIMING
+  stagger_arg = tt_counter()++ & 7;
+#endif
   hipLaunchKernelGGL((kernel<Epi, FLUSH>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
-                     group_m, (int)lo, (int)hi, epi);
+                     group_m, (int)lo, (int)hi, stagger_arg, epi);
   return ac_check_launch("gemm_hl2");
 }
 

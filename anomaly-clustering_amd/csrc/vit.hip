@@ -24,8 +24,12 @@ template <class Epi>
 static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
   if (gemm_version() == 1) return gemm::launch(A, B, M, N, K, epi, stream);
   if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
-  if (gemm_version() == 6) return gemm4::launch<Epi>(A, B, M, N, K, epi, stream);
-  return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 6) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
+  if (gemm_version() == 7) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
+  // start stagger of the first tile round, in units of 64 cycles per CU slot (see gemm_hl2.h)
+  static int stagger = -1;
+  if (stagger < 0) { const char* e = getenv("AC_STAGGER"); stagger = e ? atoi(e) : 0; }
+  return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream, 8, 0, 1, stagger);
 }
 
 __host__ __device__ inline int tpad_of(int T) { return (T + 31) / 32 * 32; }
@@ -198,6 +202,35 @@ struct EpiQK {
       store_hl32_line((which ? k : q) + (((size_t)b * H + head) * Tpad + t) * (HD * 4) + dh * 128, v);
     }
   }
+  // swapped orientation (gemm_hl2.h): 8 consecutive columns of one token row per (mi, p)
+  static constexpr bool kSwap = true;
+  template <class F>
+  __device__ void swapped(const F& f, int m_wave, int n_wave, int lane) const {
+    using S = gemm::SwapFrag;
+    int tok_b[4], tok_t[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int row = min(m_wave + S::row(mi, lane), M - 1);
+      tok_b[mi] = row / T;
+      tok_t[mi] = row - tok_b[mi] * T;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int col = n_wave + S::col8(p, lane);
+      if (col >= 2 * C) continue;
+      const int which = col / C, fcol = col - which * C, head = fcol >> 6, d = fcol & 63;
+      uint8_t* base = which ? k : q;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col), b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = f.acc[mi][2 * p][j] + b0[j]; v[4 + j] = f.acc[mi][2 * p + 1][j] + b1[j]; }
+        if (m_wave + S::row(mi, lane) < M)
+          store_hl32_8(base + (((size_t)tok_b[mi] * H + head) * Tpad + tok_t[mi]) * (HD * 4), d, v);
+      }
+    }
+  }
 };
 template <> struct gemm::EpiTraits<EpiQK> { static constexpr bool kSymmetric = false; static constexpr bool kStaged = true; };
 
@@ -257,6 +290,41 @@ struct EpiResidual {
         }
     }
   }
+  // swapped orientation (gemm_hl2.h): 8 consecutive columns of one row per (mi, p), N % 8 == 0.
+  // All residual loads first, unconditionally (row clamped), then the sums and the stores.
+  static constexpr bool kSwap = true;
+  template <class F>
+  __device__ void swapped(const F& f, int m_wave, int n_wave, int lane) const {
+    using S = gemm::SwapFrag;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int col = n_wave + S::col8(p, lane);
+      if (col >= N) continue;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col), b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+      f32x4 r0[4], r1[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const float* s = res + (size_t)min(m_wave + S::row(mi, lane), M - 1) * N + col;
+        r0[mi] = *reinterpret_cast<const f32x4*>(s);
+        r1[mi] = *reinterpret_cast<const f32x4*>(s + 4);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int row = m_wave + S::row(mi, lane);
+        f32x4 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o0[j] = r0[mi][j] + (f.acc[mi][2 * p][j] + b0[j]);
+          o1[j] = r1[mi][j] + (f.acc[mi][2 * p + 1][j] + b1[j]);
+        }
+        if (row < M) {
+          float* d = out + (size_t)row * N + col;
+          *reinterpret_cast<f32x4*>(d) = o0;
+          *reinterpret_cast<f32x4*>(d + 4) = o1;
+        }
+      }
+    }
+  }
 };
 
 // exact-erf GELU (nn.GELU default): 0.5 v (1 + erf(v / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26
@@ -312,6 +380,29 @@ struct EpiGeluHl {
 #pragma unroll
       for (int j = 0; j < 32; ++j) v[j] = gelu_erf(v[j]);
       store_hl32_line(out + (size_t)row * N * 4 + (col0 >> 5) * 128, v);
+    }
+  }
+  // swapped orientation (gemm_hl2.h): 8 consecutive columns of one row per (mi, p), N % 8 == 0
+  static constexpr bool kSwap = true;
+  template <class F>
+  __device__ void swapped(const F& f, int m_wave, int n_wave, int lane) const {
+    using S = gemm::SwapFrag;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int col = n_wave + S::col8(p, lane);
+      if (col >= N) continue;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col), b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int row = m_wave + S::row(mi, lane);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = gelu_erf(f.acc[mi][2 * p][j] + b0[j]);
+          v[4 + j] = gelu_erf(f.acc[mi][2 * p + 1][j] + b1[j]);
+        }
+        if (row < M) store_hl32_8(out + (size_t)row * N * 4, col, v);
+      }
     }
   }
 };
@@ -600,3 +691,14 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
   if ((rc = run_gemm(b.g, w->fc2_w, M, C, hidden, e2, stream))) return rc;
   return ac_check_launch("ac_vit_block");
 }
+
+#ifdef AC_TILE_TIMING
+// Diagnostic builds only (see gemm_hl2.h): reset != 0 restarts the launch-slot counter; otherwise copies
+// the [8 slots][8192 blocks][4 stamps] table to `out` and returns the number of GEMM launches since reset.
+extern "C" int ac_debug_tile_times(unsigned long long* out, int reset) {
+  if (reset) { gemm2::tt_counter() = 0; return 0; }
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm2::ac_tile_times), sizeof(gemm2::ac_tile_times)) != hipSuccess) return -1;
+  return gemm2::tt_counter();
+}
+#endif

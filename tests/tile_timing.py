@@ -1,0 +1,61 @@
+"""Per-workgroup phase timing of the ViT-block GEMMs (diagnostic; needs a -DAC_TILE_TIMING build).
+
+    hipcc ... -DAC_TILE_TIMING ... -o build_ablate/libac_timing.so      
+    AC_LIB=$PWD/build_ablate/libac_timing.so python tests/tile_timing.py 83
+
+Prints, for each of the five GEMMs of one transformer block, the median time a workgroup spends
+  launch -> first stage visible (prologue), k loop, epilogue,
+and the kernel span / number of tile rounds, i.e. what a CU spends per tile including the gap to the
+next workgroup.  Timestamps are s_memrealtime ticks (100 MHz).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "anomaly-clustering_amd", "models"))
+import acnative  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 83
+    import patchcore.vision_transformer as vits
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = vits.vit_base(patch_size=8, num_classes=0, depth=1).eval().to(dev)
+    x = torch.randn(B, 785, 768, device=dev)
+    lib = acnative.lib()
+    fn = lib.ac_debug_tile_times
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    with torch.no_grad():
+        m.blocks[0](x)
+        torch.cuda.synchronize()
+        fn(None, 1)
+        m.blocks[0](x)
+        torch.cuda.synchronize()
+    buf = np.zeros((8, 8192, 4), dtype=np.uint64)
+    n = fn(buf.ctypes.data, 0)
+    names = ["qk", "v", "proj", "fc1", "fc2"]
+    tiles_n = [12, 6, 6, 24, 6]
+    tiles_m = (B * 785 + 255) // 256
+    print("launches since reset:", n)
+    for s, (name, tn) in enumerate(zip(names, tiles_n)):
+        nb = min(tiles_m * tn, 8192)
+        t = buf[s, :nb].astype(np.int64)
+        us = lambda a: np.median(a) / 100.0
+        span = (t[:, 3].max() - t[:, 0].min()) / 100.0
+        rounds = tiles_m * tn / 256.0
+        print("%-5s blocks %5d (first %d stamped)  prologue %.2f  kloop %.2f  epilogue %.2f us (medians)   "
+              "span %.1f us / %.2f rounds = %.2f us per tile"
+              % (name, tiles_m * tn, nb, us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2]),
+                 span, rounds, span / rounds))
+        # start times of successive rounds: sort block start stamps, look at the gap structure
+        st = np.sort(t[:, 0] - t[:, 0].min()) / 100.0
+        print("      start-time quantiles (us):", " ".join("%.1f" % q for q in np.quantile(st, [0, .1, .25, .5, .75, .9, 1])))
+
+
+if __name__ == "__main__":
+    main()
