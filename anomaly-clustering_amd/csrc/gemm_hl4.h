@@ -49,6 +49,7 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   const size_t ld = (size_t)K * 4;
   const int nk = K / BK;
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+  constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
 
   int tm = 0, tn = 0;
   const int id = id_lo + blockIdx.x;
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
       const bool isA = j < 8;
       const int row = (isA ? g : g - 32) * 8 + (lane >> 3);
       const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      const uint8_t* base = isA ? A + (size_t)min(tm * BM + row, M - 1) * ld : B + (size_t)min(tn * BN + row, N - 1) * ld;
+      const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
+      const uint8_t* base = isA ? A + (size_t)min(tm * BM + row, M - 1) * ld : B + (size_t)min(tn * BN + brow, N - 1) * ld;
       src[j] = base + lc * 16;
     }
     auto issue_half = [&](int t, int half) {         // `half` is a literal at every call site
@@ -140,9 +142,15 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
 
   half8 ah[4], al[4], bh[4], bl[4];
   auto mfma3 = [&](f32x4& c, const half8& xh, const half8& xl, const half8& yh, const half8& yl) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, c, 0, 0, 0);
+    if constexpr (SWAP) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, xh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xh, c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, c, 0, 0, 0);
+    }
   };
   if constexpr (MODE == 0) {
     const bool groupB = wave >= 4;
@@ -240,7 +248,9 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
 
   const int m_wave = m0 + wm * 64, n_wave = n0 + wn * 64;
-  if constexpr (EpiTraits<Epi>::kStaged) {
+  if constexpr (SWAP) {
+    epi.swapped(f, m_wave, n_wave, lane);
+  } else if constexpr (EpiTraits<Epi>::kStaged) {
     float* t = reinterpret_cast<float*>(smem) + wave * (64 * gemm::EPI_PITCH);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)

@@ -343,6 +343,26 @@ __device__ inline float gelu_erf(float v) {
   return 0.5f * v * (v >= 0.f ? 2.0f - pe : pe);
 }
 
+// Two values at a time: the fabs/Horner/product steps map to packed fp32 instructions (v_pk_fma_f32,
+// v_pk_mul_f32 - two results per lane per issue), which is what the fc1 epilogue is bound by; same
+// operations in the same order per component as gelu_erf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 gelu_erf2(f32x2 v) {
+  const f32x2 z = __builtin_elementwise_abs(v) * 0.70710678118654752440f;
+  const f32x2 den = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  f32x2 poly = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{1.421413741f, 1.421413741f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{-0.284496736f, -0.284496736f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.254829592f, 0.254829592f});
+  poly *= t;
+  const f32x2 a = -z * z * 1.44269504088896340736f;
+  const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  const f32x2 pe = poly * e;
+  const f32x2 hv = 0.5f * v;
+  return f32x2{hv.x * (v.x >= 0.f ? 2.0f - pe.x : pe.x), hv.y * (v.y >= 0.f ? 2.0f - pe.y : pe.y)};
+}
+
 // g = gelu(acc + bias) (exact erf form, nn.GELU default) -> hl32 [M, N]
 struct EpiGeluHl {
   const float* bias; uint8_t* out; int M, N;
@@ -397,9 +417,11 @@ struct EpiGeluHl {
         const int row = m_wave + S::row(mi, lane);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = gelu_erf(f.acc[mi][2 * p][j] + b0[j]);
-          v[4 + j] = gelu_erf(f.acc[mi][2 * p + 1][j] + b1[j]);
+        for (int j = 0; j < 4; j += 2) {
+          const f32x2 g0 = gelu_erf2(f32x2{f.acc[mi][2 * p][j] + b0[j], f.acc[mi][2 * p][j + 1] + b0[j + 1]});
+          const f32x2 g1 = gelu_erf2(f32x2{f.acc[mi][2 * p + 1][j] + b1[j], f.acc[mi][2 * p + 1][j + 1] + b1[j + 1]});
+          v[j] = g0.x; v[j + 1] = g0.y;
+          v[4 + j] = g1.x; v[5 + j] = g1.y;
         }
         if (row < M) store_hl32_8(out + (size_t)row * N * 4, col, v);
       }
