@@ -1,0 +1,268 @@
+// Split-fp16 MFMA GEMM, 256x256x32 tiles on 8 waves (2 per SIMD)  -  AC_GEMM=8.
+//
+// Why: tile-phase timing of gemm_hl2.h (tests/tile_timing.py) shows its k loop runs
+// at 1.25-1.5 us per stage where the MFMAs need 0.85: with a 3-slot ring only two 48 KB stages are in
+// flight per CU, and at the ~2.5 us global->LDS latency seen under load that is 68 % of the 56 GB/s per
+// CU the tile consumes (Little's law) - exactly the measured efficiency.  A 256x256 tile needs half the
+// bytes per FLOP, so the same ~100 KB in flight covers the latency with room to spare.
+//
+// Layout: wave (wm, wn) of a 4 x 2 grid owns 64 rows x 128 columns:
+//   acc   4 x 8 tiles of 16x16 (v_mfma_f32_16x16x32_f16)            128 registers
+//   B     all 8 column fragments (hi + lo) of the stage               64
+//   A     one row fragment (hi + lo), double buffered                 16
+// and runs ONE continuous stream of row steps (24 MFMAs each): the next A fragment is read during the
+// current step; in the LAST step of a stage each B fragment is re-read for the next stage right after
+// its final MFMA (21 MFMAs before its first use), so there is no fragment-load bubble and no second B
+// register set.  No second accumulator either: callers that need two-level accumulation use the
+// chunk-norm form (alpha.hip).
+//
+// LDS (160 KB) = five 32 KB half-tiles: A in a 3-slot ring, B in a 2-slot ring, filled by
+// global_load_lds, 4 instructions per wave per half-tile.  Per stage t two barriers:
+//   X(t), before the last row step: everybody's share of A(t+1), B(t+1) has landed; nobody reads A(t)
+//         any more                                          -> A(t+3) goes into A(t)'s slot (2 stages of cover)
+//   Y(t+1), after it: every wave holds B(t+1) in registers   -> B(t+3) goes into B(t+1)'s slot (1.75 stages)
+#pragma once
+#include "gemm_hl2.h"
+
+namespace gemm5 {
+
+using gemm::EpiTraits;
+using gemm2::gptr_t;
+using gemm2::lptr_t;
+using gemm2::tile_off;
+using Frag = gemm::FragT<16>;
+
+constexpr int BM = 256, BN = 256, BK = 32, THREADS = 512;
+constexpr int HALF = 256 * 128;                 // one operand half-tile: 256 rows x 128 B
+constexpr int A_SLOTS = 3, B_SLOTS = 2;
+constexpr int LDS_BYTES = (A_SLOTS + B_SLOTS) * HALF;   // 160 KB
+
+// Timing-only diagnostic builds (results are wrong): -DAC_ABLATE5=1 no DMA in the k loop, 2 no fragment
+// reads in the k loop, 4 no MFMAs, 8 no barriers in the k loop (combinable).  0 in every shipped build.
+#ifndef AC_ABLATE5
+#define AC_ABLATE5 0
+#endif
+
+// Map a linear tile id to (tm, tn); false for a hole of the folded symmetric grid.  Symmetric problems
+// run the upper triangle (tm <= tn) of the T x T tile matrix folded into a ceil(T/2) x (T+1) rectangle:
+// folded row p holds row p (T-p tiles) followed by row T-1-p (p+1 tiles).
+template <class Epi>
+__device__ inline bool tile_of(int id, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
+  gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {
+      const int T = tiles_n - 1, p = tm, c = tn;
+      if (c < T - p) { tm = p; tn = p + c; }
+      else {
+        if (2 * p == T - 1) return false;          // odd T: the middle row is paired with itself
+        tm = T - 1 - p; tn = tm + (c - (T - p));
+      }
+    }
+  }
+  return true;
+}
+
+template <class Epi>
+__global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                     int M, int N, int K, int tiles_m, int tiles_n, int group_m,
+                                                     int id_lo, int id_hi, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const Aring = smem;
+  uint8_t* const Bring = smem + A_SLOTS * HALF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const size_t ld = (size_t)K * 4;
+  const int nk = K / BK;
+  constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
+
+  int tm = 0, tn = 0;
+  const int id = id_lo + blockIdx.x;
+  if (id >= id_hi || !tile_of(id, tiles_m, tiles_n, group_m, epi, tm, tn)) return;   // block-uniform
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // DMA map: a half-tile is 32 wave-instructions of 1 KB (8 rows each).  Wave w issues g = 8j + w,
+  // j = 0..3.  Lane l lands in slot l of the instruction: row 8g + (l>>3), physical chunk l&7, so it
+  // fetches logical chunk (l&7) ^ ((row>>1)&7) of that row.  Swapped orientation: LDS row r of the B
+  // tile holds global row perm(r) (gemm_hl.h).
+  const uint8_t* srcA[4];
+  const uint8_t* srcB[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 8 + wave) * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
+    srcA[j] = A + (size_t)min(m0 + row, M - 1) * ld + lc * 16;
+    srcB[j] = B + (size_t)min(n0 + brow, N - 1) * ld + lc * 16;
+  }
+  auto dmaA = [&](int t, int slot) {
+    const size_t ko = (size_t)t * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + ko), (lptr_t)(Aring + slot * HALF + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+  auto dmaB = [&](int t, int slot) {
+    const size_t ko = (size_t)t * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + ko), (lptr_t)(Bring + slot * HALF + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+  auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+
+  // fragment offsets: 16-row tile t of this wave's rows is base + t * 2048 bytes (the XOR swizzle term
+  // (row >> 1) & 7 is unchanged by +16 rows)
+  const int a_hi = tile_off(wm * 64 + (lane & 15), (lane >> 4)), a_lo = tile_off(wm * 64 + (lane & 15), 4 + (lane >> 4));
+  const int b_hi = tile_off(wn * 128 + (lane & 15), (lane >> 4)), b_lo = tile_off(wn * 128 + (lane & 15), 4 + (lane >> 4));
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[mi][ni][i] = 0.f;
+
+  // prologue: A(0) B(0) A(1) B(1) A(2) in that order; the first two must have landed
+  dmaA(0, 0);
+  dmaB(0, 0);
+  if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
+  if (nk > 2) dmaA(2, 2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+  half8 bh[8], bl[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    bh[t] = *reinterpret_cast<const half8*>(Bring + b_hi + t * 2048);
+    bl[t] = *reinterpret_cast<const half8*>(Bring + b_lo + t * 2048);
+  }
+  half8 ah = *reinterpret_cast<const half8*>(Aring + a_hi), al = *reinterpret_cast<const half8*>(Aring + a_lo);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  barrier();                                     // Y(0): B(0) is in registers everywhere
+  if (nk > 2) dmaB(2, 0);
+  // (Tried: every wave issuing its share at its own eighth of the stage instead of all waves right after
+  // the barriers - 3 % slower on the K = 4096 all-pairs problem, equal on the ViT GEMMs.)
+
+  auto mfma3 = [&](f32x4& c, const half8& xh, const half8& xl, const half8& yh, const half8& yl) {
+    if constexpr (SWAP) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, xh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xh, c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, c, 0, 0, 0);
+    }
+  };
+
+  int sa = 0;                                    // A slot of the current stage (kt % 3)
+  auto stage = [&](int kt, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;   // branch-free body while three more stages follow
+    const bool more1 = STEADY || kt + 1 < nk, more2 = STEADY || kt + 2 < nk, more3 = STEADY || kt + 3 < nk;
+    const int sa1 = sa == 2 ? 0 : sa + 1;        // (kt + 1) % 3
+    const uint8_t* As = Aring + sa * HALF;
+    const uint8_t* An = Aring + sa1 * HALF;
+    const uint8_t* Bn = Bring + ((kt + 1) & 1) * HALF;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (mi == 3 && more1) {
+        // own share of A(kt+1), B(kt+1) landed: A(kt+2), B(kt+2) (4 each) may still fly
+        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(AC_ABLATE5 & 8)) barrier();        // X(kt)
+        if (more3 && !(AC_ABLATE5 & 1)) dmaA(kt + 3, sa);
+      }
+      half8 nh = ah, nl = al;
+      if (AC_ABLATE5 & 2) {
+      } else if (mi < 3) {
+        nh = *reinterpret_cast<const half8*>(As + a_hi + (mi + 1) * 2048);
+        nl = *reinterpret_cast<const half8*>(As + a_lo + (mi + 1) * 2048);
+      } else if (more1) {
+        nh = *reinterpret_cast<const half8*>(An + a_hi);
+        nl = *reinterpret_cast<const half8*>(An + a_lo);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        if (!(AC_ABLATE5 & 4)) mfma3(acc[mi][ni], ah, al, bh[ni], bl[ni]);
+        if (mi == 3 && more1 && !(AC_ABLATE5 & 2)) {
+          bh[ni] = *reinterpret_cast<const half8*>(Bn + b_hi + ni * 2048);
+          bl[ni] = *reinterpret_cast<const half8*>(Bn + b_lo + ni * 2048);
+        }
+      }
+      ah = nh; al = nl;
+    }
+    if (more1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(AC_ABLATE5 & 8)) barrier();          // Y(kt+1)
+      if (more3 && !(AC_ABLATE5 & 1)) dmaB(kt + 3, (kt + 1) & 1);
+    }
+    sa = sa1;
+  };
+  int kt = 0;
+  for (; kt + 3 < nk; ++kt) stage(kt, std::true_type{});
+  for (; kt < nk; ++kt) stage(kt, std::false_type{});
+  barrier();                                     // ring reads done before an epilogue reuses LDS
+
+  // epilogue: the 64x128 accumulator as two 64x64 fragments of the common epilogue interface
+  const int m_wave = m0 + wm * 64;
+#pragma unroll
+  for (int no = 0; no < 2; ++no) {
+    Frag f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) f.acc[mi][ni] = acc[mi][no * 4 + ni];
+    const int n_wave = n0 + wn * 128 + no * 64;
+    if constexpr (SWAP) {
+      epi.swapped(f, m_wave, n_wave, lane);
+    } else if constexpr (EpiTraits<Epi>::kSymmetric) {
+      if (epi.symmetric) {
+        // 64-row block rb against 64-column block cb of the symmetric matrix: rb < cb reduce both
+        // ways, rb == cb one way, rb > cb (lower part of a diagonal tile) is its mirror image's job
+        const int rb = tm * 4 + wm, cb = tn * 4 + wn * 2 + no;
+        if (rb <= cb) epi(f, m_wave, n_wave, lane);
+        if (rb < cb) epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65));
+      } else {
+        epi(f, m_wave, n_wave, lane);
+      }
+    } else {
+      epi(f, m_wave, n_wave, lane);
+    }
+  }
+}
+
+template <class Epi>
+inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                  int group_m = 4, int part = 0, int nparts = 1) {
+  if (M <= 0 || N <= 0) return AC_OK;
+  if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl5: K=%d must be a positive multiple of 32", K);
+  if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl5: bad part %d/%d", part, nparts);
+  int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {                           // folded upper triangle (see tile_of)
+      if (M != N) return ac_fail(AC_EINVAL, "gemm_hl5: symmetric epilogue needs M == N");
+      const int T = tiles_m;
+      tiles_m = (T + 1) / 2;
+      tiles_n = T + 1;
+    }
+  }
+  long long total = (long long)tiles_m * tiles_n;
+  if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl5: grid too large");
+  static bool attr_set = false;                    // per instantiation
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  long long lo = (total * part / nparts) & ~7LL;
+  long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
+  if (hi <= lo) return AC_OK;
+  hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
+                     static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
+                     group_m, (int)lo, (int)hi, epi);
+  return ac_check_launch("gemm_hl5");
+}
+
+}  // namespace gemm5

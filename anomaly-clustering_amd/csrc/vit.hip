@@ -10,14 +10,17 @@
 // conversion pass.
 #include "gemm_hl3.h"
 #include "gemm_hl4.h"
+#include "gemm_hl5.h"
 #include <stdlib.h>
 
 constexpr int HD = 64;          // head dim (all DINO ViTs)
 
-// AC_GEMM=1 selects the first-generation 128x128 register-staged kernel (A/B runs); default: LDS-DMA ring.
+// Default: the 256x256 kernel (gemm_hl5.h).  AC_GEMM selects another generation for same-box A/B runs:
+// 1 = 128x128 register staged (gemm_hl.h), 3 = 256x128 LDS-DMA ring (gemm_hl2.h), 5 = 256x256 on 4 waves
+// (gemm_hl3.h), 6 / 7 = loader-specialised 256x128 (gemm_hl4.h), 8 = gemm_hl5.h.
 static int gemm_version() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
+  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 8; }
   return v;
 }
 template <class Epi>
@@ -26,6 +29,7 @@ static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi
   if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
   if (gemm_version() == 6) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
   if (gemm_version() == 7) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
+  if (gemm_version() != 3) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
   // start stagger of the first tile round, in units of 64 cycles per CU slot (see gemm_hl2.h)
   static int stagger = -1;
   if (stagger < 0) { const char* e = getenv("AC_STAGGER"); stagger = e ? atoi(e) : 0; }

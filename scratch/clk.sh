@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for tag in full ab11 ab1; do
+  case $tag in full) L=$R/anomaly-clustering_amd/models/acnative/libac_hip.so;; ab11) L=$R/build_ablate/libac5_ablate11.so;; ab1) L=$R/build_ablate/libac5_ablate1.so;; esac
+  AC_LIB=$L AC_GEMM=8 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/clk_$tag -- python3 $R/tests/perf_probe.py alpha 48 > $R/gpurun_out/clk_$tag.log 2>&1
+  tail -1 $R/gpurun_out/clk_$tag.log
+done
