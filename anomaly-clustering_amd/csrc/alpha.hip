@@ -155,7 +155,7 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   // experimental loader-specialised kernel: single accumulation (timing studies)
   if (v == 6) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 7) return gemm4::launch<EpiPairMin, 1>(A, B, M, N, K, epi, stream, group_m, part, nparts);
-  if (v == 8) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, gm > 0 ? gm : 4, part, nparts);
+  if (v == 8 && gemm5::fits(M, N, K)) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, gm > 0 ? gm : 4, part, nparts);
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
 }
 
@@ -459,3 +459,13 @@ extern "C" int ac_pdist(const float* X, int64_t N, int D, double* out, void* str
   hipLaunchKernelGGL(pdist_kernel, dim3(t, t), dim3(256), 0, as_stream(stream), X, N, D, out);
   return ac_check_launch("pdist");
 }
+
+#ifdef AC_TILE_TIMING
+// Diagnostic builds only (gemm_hl5.h): per-workgroup [k-loop cycles, X wait, Y wait, stages] of the last
+// gemm_hl5 launch made from this translation unit.
+extern "C" int ac_debug_wait_times(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm5::ac_wait_times), sizeof(gemm5::ac_wait_times)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

@@ -17,7 +17,7 @@
 // chunk-norm form (alpha.hip).
 //
 // LDS (160 KB) = five 32 KB half-tiles: A in a 3-slot ring, B in a 2-slot ring, filled by
-// global_load_lds, 4 instructions per wave per half-tile.  Per stage t two barriers:
+// global_load_lds, 8 instructions per half-tile from each of the waves 0-3.  Per stage t two barriers:
 //   X(t), before the last row step: everybody's share of A(t+1), B(t+1) has landed; nobody reads A(t)
 //         any more                                          -> A(t+3) goes into A(t)'s slot (2 stages of cover)
 //   Y(t+1), after it: every wave holds B(t+1) in registers   -> B(t+3) goes into B(t+1)'s slot (1.75 stages)
@@ -41,6 +41,16 @@ constexpr int LDS_BYTES = (A_SLOTS + B_SLOTS) * HALF;   // 160 KB
 // reads in the k loop, 4 no MFMAs, 8 no barriers in the k loop (combinable).  0 in every shipped build.
 #ifndef AC_ABLATE5
 #define AC_ABLATE5 0
+#endif
+// -DAC_TILE_TIMING: wave 0 of every workgroup accumulates the shader-clock cycles it spends waiting at
+// X (DMA landed + barrier) and at Y (fragment reads done + barrier), and its total k-loop cycles.
+#ifdef AC_TILE_TIMING
+static __device__ unsigned long long ac_wait_times[8192 * 8];
+#define AC_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
+#define AC_TACC(v) v += __builtin_readcyclecounter() - t0_
+#else
+#define AC_T0()
+#define AC_TACC(v)
 #endif
 
 // Map a linear tile id to (tm, tn); false for a hole of the folded symmetric grid.  Symmetric problems
@@ -81,31 +91,44 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   if (id >= id_hi || !tile_of(id, tiles_m, tiles_n, group_m, epi, tm, tn)) return;   // block-uniform
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // DMA map: a half-tile is 32 wave-instructions of 1 KB (8 rows each).  Wave w issues g = 8j + w,
-  // j = 0..3.  Lane l lands in slot l of the instruction: row 8g + (l>>3), physical chunk l&7, so it
-  // fetches logical chunk (l&7) ^ ((row>>1)&7) of that row.  Swapped orientation: LDS row r of the B
-  // tile holds global row perm(r) (gemm_hl.h).
-  const uint8_t* srcA[4];
-  const uint8_t* srcB[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (j * 8 + wave) * 8 + (lane >> 3);
-    const int lc = (lane & 7) ^ ((row >> 1) & 7);
-    const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
-    srcA[j] = A + (size_t)min(m0 + row, M - 1) * ld + lc * 16;
-    srcB[j] = B + (size_t)min(n0 + brow, N - 1) * ld + lc * 16;
-  }
+  // DMA map: a half-tile is 32 wave-instructions of 1 KB (8 rows each).  Only waves 0-3 issue them
+  // (see below): wave w issues g = 4j + w, j = 0..7.  Lane l lands in slot l of the instruction: row
+  // 8g + (l>>3), physical chunk l&7, so it fetches logical chunk (l&7) ^ ((row>>1)&7) of that row.
+  // Swapped orientation: LDS row r of the B tile holds global row perm(r) (gemm_hl.h).  Offsets are
+  // 32-bit (launch() checks the operands are below 4 GiB).
+  //
+  // Who issues: the SIMD's arbiter serves its older wave first, so of the two waves of a SIMD (w, w+4)
+  // wave w runs ahead and parks at the next barrier, and whatever wave w+4 has to do besides MFMAs while
+  // it catches up alone is exposed (wait-time stamps, tests/wait_timing.py: wave 0 idles ~800 cycles at
+  // each barrier, wave 4 never waits; stage time = 2 x MFMA time + the younger wave's other work).  The
+  // older wave's other work is free - the younger one issues MFMAs meanwhile - so ALL the DMA goes to
+  // waves 0-3, which also get the explicit higher priority.
+  const bool loader = wave < 4;
+  if (loader) __builtin_amdgcn_s_setprio(2);
+  // Row r = 32j + 8(w&3) + (l>>3); (r>>1)&7 and with it the chunk swizzle do not depend on j, so the
+  // per-lane state is one row number and one chunk offset and the address is rebuilt per instruction
+  // (3 VALU operations on a wave whose stalls are hidden anyway) instead of living in 16 registers.
+  const int row0 = (wave & 3) * 8 + (lane >> 3);
+  const unsigned lc16 = (unsigned)((lane & 7) ^ ((row0 >> 1) & 7)) * 16u;
   auto dmaA = [&](int t, int slot) {
-    const size_t ko = (size_t)t * 128;
+    if (!loader) return;
+    const uint8_t* base = A + (size_t)t * 128;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + ko), (lptr_t)(Aring + slot * HALF + (j * 8 + wave) * 1024), 16, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+      const unsigned off = (unsigned)min(m0 + row0 + 32 * j, M - 1) * (unsigned)ld + lc16;
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(Aring + slot * HALF + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
+    }
   };
   auto dmaB = [&](int t, int slot) {
-    const size_t ko = (size_t)t * 128;
+    if (!loader) return;
+    const uint8_t* base = B + (size_t)t * 128;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + ko), (lptr_t)(Bring + slot * HALF + (j * 8 + wave) * 1024), 16, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+      const int row = row0 + 32 * j;
+      const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
+      const unsigned off = (unsigned)min(n0 + brow, N - 1) * (unsigned)ld + lc16;
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(Bring + slot * HALF + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
+    }
   };
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
 
@@ -127,8 +150,8 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   dmaB(0, 0);
   if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
   if (nk > 2) dmaA(2, 2);
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
   half8 bh[8], bl[8];
@@ -141,9 +164,6 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   barrier();                                     // Y(0): B(0) is in registers everywhere
   if (nk > 2) dmaB(2, 0);
-  // (Tried: every wave issuing its share at its own eighth of the stage instead of all waves right after
-  // the barriers - 3 % slower on the K = 4096 all-pairs problem, equal on the ViT GEMMs.)
-
   auto mfma3 = [&](f32x4& c, const half8& xh, const half8& xl, const half8& yh, const half8& yl) {
     if constexpr (SWAP) {
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, xh, c, 0, 0, 0);
@@ -157,6 +177,10 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   };
 
   int sa = 0;                                    // A slot of the current stage (kt % 3)
+#ifdef AC_TILE_TIMING
+  unsigned long long tx = 0, ty = 0, tx1 = 0, ty1 = 0, td = 0;
+  const unsigned long long tloop = __builtin_readcyclecounter();
+#endif
   auto stage = [&](int kt, auto steady) {
     constexpr bool STEADY = decltype(steady)::value;   // branch-free body while three more stages follow
     const bool more1 = STEADY || kt + 1 < nk, more2 = STEADY || kt + 2 < nk, more3 = STEADY || kt + 3 < nk;
@@ -167,12 +191,15 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       if (mi == 3 && more1) {
-        // own share of A(kt+1), B(kt+1) landed: A(kt+2), B(kt+2) (4 each) may still fly
-        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // own share of A(kt+1), B(kt+1) landed: A(kt+2), B(kt+2) (8 each) may still fly
+        AC_T0();
+        if (more2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        AC_TACC(tx1);
         if (!(AC_ABLATE5 & 8)) barrier();        // X(kt)
-        if (more3 && !(AC_ABLATE5 & 1)) dmaA(kt + 3, sa);
+        AC_TACC(tx);
+        if (more3 && !(AC_ABLATE5 & 1)) { AC_T0(); dmaA(kt + 3, sa); AC_TACC(td); }
       }
       half8 nh = ah, nl = al;
       if (AC_ABLATE5 & 2) {
@@ -194,8 +221,11 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
       ah = nh; al = nl;
     }
     if (more1) {
+      AC_T0();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AC_TACC(ty1);
       if (!(AC_ABLATE5 & 8)) barrier();          // Y(kt+1)
+      AC_TACC(ty);
       if (more3 && !(AC_ABLATE5 & 1)) dmaB(kt + 3, (kt + 1) & 1);
     }
     sa = sa1;
@@ -204,6 +234,13 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   for (; kt + 3 < nk; ++kt) stage(kt, std::true_type{});
   for (; kt < nk; ++kt) stage(kt, std::false_type{});
   barrier();                                     // ring reads done before an epilogue reuses LDS
+#ifdef AC_TILE_TIMING
+  if ((tid == 0 || tid == 256) && blockIdx.x < 4096) {   // waves 0 and 4: the two waves of one SIMD
+    unsigned long long* o = ac_wait_times + (blockIdx.x * 2 + (tid >> 8)) * 8;
+    o[0] = __builtin_readcyclecounter() - tloop;
+    o[1] = tx; o[2] = ty; o[3] = nk; o[4] = tx1; o[5] = ty1; o[6] = td;
+  }
+#endif
 
   // epilogue: the 64x128 accumulator as two 64x64 fragments of the common epilogue interface
   const int m_wave = m0 + wm * 64;
@@ -233,10 +270,16 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
 }
 
+// True when both operands fit this kernel's 32-bit row offsets.
+inline bool fits(int M, int N, int K) {
+  return (unsigned long long)(M > N ? M : N) * (unsigned long long)K * 4ull < 0xffff0000ull;
+}
+
 template <class Epi>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 4, int part = 0, int nparts = 1) {
   if (M <= 0 || N <= 0) return AC_OK;
+  if (!fits(M, N, K)) return ac_fail(AC_EINVAL, "gemm_hl5: operand larger than 4 GiB");
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl5: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl5: bad part %d/%d", part, nparts);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
