@@ -13,8 +13,11 @@
 // and runs ONE continuous stream of row steps (24 MFMAs each): the next A fragment is read during the
 // current step; in the LAST step of a stage each B fragment is re-read for the next stage right after
 // its final MFMA (21 MFMAs before its first use), so there is no fragment-load bubble and no second B
-// register set.  No second accumulator either: callers that need two-level accumulation use the
-// chunk-norm form (alpha.hip).
+// register set.  No room for a second accumulator: the all-pairs kernel, which needs two-level
+// accumulation for fp32-grade distances, stays on gemm_hl2.h.  (Tried: folding -(|a|^2 + |b|^2)/2 into the
+// operands as an extra k stage per 1024 features so that one accumulator holds -|a-b|^2/2: 6.5e-5 from the
+// fp64 truth against 1.8e-5 with the second accumulator - the error follows the +-175 swing inside a chunk,
+// and the stage density that would fix it costs more MFMA work than this kernel saves.)
 //
 // LDS (160 KB) = five 32 KB half-tiles: A in a 3-slot ring, B in a 2-slot ring, filled by
 // global_load_lds, 8 instructions per half-tile from each of the waves 0-3.  Per stage t two barriers:
@@ -82,9 +85,9 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const size_t ld = (size_t)K * 4;
-  const int nk = K / BK;
   constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
+  const int nk = K / BK;
+  const size_t ld = (size_t)K * 4;
 
   int tm = 0, tn = 0;
   const int id = id_lo + blockIdx.x;
@@ -94,8 +97,7 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   // DMA map: a half-tile is 32 wave-instructions of 1 KB (8 rows each).  Only waves 0-3 issue them
   // (see below): wave w issues g = 4j + w, j = 0..7.  Lane l lands in slot l of the instruction: row
   // 8g + (l>>3), physical chunk l&7, so it fetches logical chunk (l&7) ^ ((row>>1)&7) of that row.
-  // Swapped orientation: LDS row r of the B tile holds global row perm(r) (gemm_hl.h).  Offsets are
-  // 32-bit (launch() checks the operands are below 4 GiB).
+  // Swapped orientation: LDS row r of the B tile holds global row perm(r) (gemm_hl.h).
   //
   // Who issues: the SIMD's arbiter serves its older wave first, so of the two waves of a SIMD (w, w+4)
   // wave w runs ahead and parks at the next barrier, and whatever wave w+4 has to do besides MFMAs while
@@ -112,21 +114,21 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   const unsigned lc16 = (unsigned)((lane & 7) ^ ((row0 >> 1) & 7)) * 16u;
   auto dmaA = [&](int t, int slot) {
     if (!loader) return;
-    const uint8_t* base = A + (size_t)t * 128;
+    const uint8_t* base = A + (size_t)t * 128 + lc16;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const unsigned off = (unsigned)min(m0 + row0 + 32 * j, M - 1) * (unsigned)ld + lc16;
+      const size_t off = (size_t)min(m0 + row0 + 32 * j, M - 1) * ld;
       __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(Aring + slot * HALF + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
     }
   };
   auto dmaB = [&](int t, int slot) {
     if (!loader) return;
-    const uint8_t* base = B + (size_t)t * 128;
+    const uint8_t* base = B + (size_t)t * 128 + lc16;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = row0 + 32 * j;
       const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
-      const unsigned off = (unsigned)min(n0 + brow, N - 1) * (unsigned)ld + lc16;
+      const size_t off = (size_t)min(n0 + brow, N - 1) * ld;
       __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(Bring + slot * HALF + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
     }
   };
@@ -270,16 +272,10 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
 }
 
-// True when both operands fit this kernel's 32-bit row offsets.
-inline bool fits(int M, int N, int K) {
-  return (unsigned long long)(M > N ? M : N) * (unsigned long long)K * 4ull < 0xffff0000ull;
-}
-
 template <class Epi>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 4, int part = 0, int nparts = 1) {
   if (M <= 0 || N <= 0) return AC_OK;
-  if (!fits(M, N, K)) return ac_fail(AC_EINVAL, "gemm_hl5: operand larger than 4 GiB");
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl5: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl5: bad part %d/%d", part, nparts);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;

@@ -29,7 +29,7 @@ static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi
   if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
   if (gemm_version() == 6) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
   if (gemm_version() == 7) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
-  if (gemm_version() != 3 && gemm5::fits(M, N, K)) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
+  if (gemm_version() != 3) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
   // start stagger of the first tile round, in units of 64 cycles per CU slot (see gemm_hl2.h)
   static int stagger = -1;
   if (stagger < 0) { const char* e = getenv("AC_STAGGER"); stagger = e ? atoi(e) : 0; }
