@@ -440,19 +440,31 @@ template <> struct gemm::EpiTraits<EpiGeluHl> { static constexpr bool kSymmetric
 // the lane, so the softmax max/sum over keys are in-lane reductions plus one lane-half exchange,
 // and the exponentiated tile is already laid out as the B operand of O^T += V^T P^T
 // (accumulator-as-operand, k order 16s + 8(j>>2) + 4h + (j&3); V^T fragments are read in that order).
-// Block = 4 waves x 32 queries; K and V^T tiles of 32 keys are staged once per block in LDS.
+// Block = 4 waves x 32 queries.  K and V^T tiles of 32 keys go global -> LDS by global_load_lds into a
+// double buffer, one tile ahead of the MFMAs (no staging registers: a register double buffer cost a wave
+// of occupancy and ran slower; without any prefetch the ~1.5 us load latency of every tile was exposed
+// and the MFMA pipe sat at 31 %).
+// Key order: MFMA row rho of the S^T tile holds key pi(rho) = rho with bits 2 and 3 swapped.  The
+// accumulator-as-operand trick feeds P^T to the second product with k index j <-> accumulator row
+// 16s + 8(j>>2) + 4h + (j&3); with pi that row is key 16s + 8h + j, i.e. eight CONSECUTIVE keys per lane, so
+// a V^T fragment is one 16-byte read of the plain hl32 row (and the tile can be DMA'd as it lies in HBM).
 constexpr int ATT_Q = 128, ATT_KT = 32;
-constexpr int ATT_LDS = 4 * 32 * 65 * 4;   // epilogue transpose buffer (>= 16 KB of K/V tiles)
+constexpr int ATT_TILE = 16384;            // K tile [32 keys][256 B] + V^T tile [64 d][128 B]
+constexpr int ATT_LDS = 4 * 32 * 65 * 4;   // epilogue transpose buffer, >= the two tile buffers (32 KB)
+static_assert(ATT_LDS >= 2 * ATT_TILE, "tile double buffer must fit");
 
-__global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ K,
+__global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ K,
                                                         const uint8_t* __restrict__ Vt, uint8_t* __restrict__ O,
                                                         int T, int Tpad, int H, float scale) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[ATT_LDS];
-  // per buffer: K tile [32 keys][256 B] (16-byte slots XOR (row & 15)) then V^T tile [64 d][128 B]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  // per buffer: K tile, 16-byte slots XOR (row & 15); then V^T tile, 16-byte chunks XOR ((d >> 1) & 7)
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
   const int q0 = blockIdx.x * ATT_Q + wave * 32;
   const int C = H * HD;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
 
   // Q fragments (B operand): lane = query column, element j <-> feature 16s + 8h + j
   half8 qh[4], ql[4];
@@ -474,42 +486,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
   const uint8_t* Kbase = K + (size_t)bh * Tpad * (HD * 4);
   const uint8_t* Vbase = Vt + (size_t)bh * HD * ((size_t)Tpad * 4);
   const int ntiles = (T + ATT_KT - 1) / ATT_KT;
-  // One K / V^T tile in LDS at a time.  (A register-prefetched double buffer was tried: +16 VGPRs took
-  // the kernel from 3 to 2 waves per SIMD and it ran 7 % slower; other workgroups cover the load latency.)
-  u32x4 pk[2], pv[2];
-  auto gload = [&](int kt) {
+  // DMA map (1 KB per wave-instruction, lane l lands in 16-byte slot l of it; the swizzle goes on the
+  // SOURCE address).  K tile: instruction g = rows 4g..4g+3; V^T tile: instruction g = rows 8g..8g+7.
+  // Wave w issues g = w and w + 4 of each.
+  const uint8_t* ksrc[2];
+  const uint8_t* vsrc[2];
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      int row = (tid >> 4) + rep * 16, slot = tid & 15;
-      pk[rep] = *reinterpret_cast<const u32x4*>(Kbase + (size_t)(kt * ATT_KT + row) * (HD * 4) + slot * 16);
-      int vrow = (tid >> 3) + rep * 32, vslot = tid & 7;
-      pv[rep] = *reinterpret_cast<const u32x4*>(Vbase + (size_t)vrow * ((size_t)Tpad * 4) + (size_t)kt * 128 + vslot * 16);
+  for (int j = 0; j < 2; ++j) {
+    const int g = wave + 4 * j;
+    const int krow = 4 * g + (lane >> 4), kslot = (lane & 15) ^ (krow & 15);
+    ksrc[j] = Kbase + (size_t)krow * (HD * 4) + kslot * 16;
+    const int vrow = 8 * g + (lane >> 3), vchunk = (lane & 7) ^ ((vrow >> 1) & 7);
+    vsrc[j] = Vbase + (size_t)vrow * ((size_t)Tpad * 4) + vchunk * 16;
+  }
+  auto dma_tile = [&](int kt) {
+    uint8_t* buf = lds + (kt & 1) * ATT_TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = wave + 4 * j;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[j] + (size_t)kt * (ATT_KT * HD * 4)), (lptr_t)(buf + g * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (size_t)kt * 128), (lptr_t)(buf + 8192 + g * 1024), 16, 0, 0);
     }
   };
-  auto lstore = [&](int buf) {
-    uint8_t* Kb = lds + buf * 16384;
-    uint8_t* Vb = Kb + 8192;
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      int row = (tid >> 4) + rep * 16, slot = tid & 15;
-      *reinterpret_cast<u32x4*>(Kb + row * 256 + ((slot ^ (row & 15)) << 4)) = pk[rep];
-      // V^T image: 8-byte granule g of row d lives at granule g ^ ((d>>1)&15): conflict-free ds_read_b64
-      // for the 32 rows a lane group reads.  A 16-byte store covers granules 2j, 2j+1: they stay in one
-      // 16-byte slot, swapped when the XOR value is odd.
-      int vrow = (tid >> 3) + rep * 32, vslot = tid & 7, x = (vrow >> 1) & 15;
-      u32x4 w = pv[rep];
-      if (x & 1) { u32x4 t = w; w[0] = t[2]; w[1] = t[3]; w[2] = t[0]; w[3] = t[1]; }
-      *reinterpret_cast<u32x4*>(Vb + vrow * 128 + ((vslot ^ (x >> 1)) << 4)) = w;
-    }
-  };
+  const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): key held by MFMA row r
+  dma_tile(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * ATT_KT;
-    const uint8_t* Ks = lds;
+    const uint8_t* Ks = lds + (kt & 1) * ATT_TILE;
     const uint8_t* Vs = Ks + 8192;
-    __syncthreads();                       // previous tile fully consumed
-    gload(kt);
-    lstore(0);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile kt has landed
+    __syncthreads();                                   // ... everybody's has; tile kt-1 is fully consumed
+    if (kt + 1 < ntiles) dma_tile(kt + 1);             // flies under this tile's MFMAs
 
     // S^T tile [32 keys x 32 queries]
     f32x16 s_acc;
@@ -518,8 +525,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int slot = (s >> 1) * 8 + (s & 1) * 2 + h;
-      half8 kh = *reinterpret_cast<const half8*>(Ks + r * 256 + ((slot ^ (r & 15)) << 4));
-      half8 kl = *reinterpret_cast<const half8*>(Ks + r * 256 + (((slot + 4) ^ (r & 15)) << 4));
+      half8 kh = *reinterpret_cast<const half8*>(Ks + pr * 256 + ((slot ^ (pr & 15)) << 4));
+      half8 kl = *reinterpret_cast<const half8*>(Ks + pr * 256 + (((slot + 4) ^ (pr & 15)) << 4));
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s_acc, 0, 0, 0);
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s_acc, 0, 0, 0);
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s_acc, 0, 0, 0);
@@ -527,11 +534,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
     // online softmax over the key axis (registers + the other lane half), in the log2 domain:
     // p = 2^(s*c - m) with c = scale*log2(e) - one FMA and one v_exp_f32 per score.  Only the last
     // tile has padded keys (block-uniform branch); the O / l rescale is skipped (wave-uniform
-    // branch) whenever no lane's running maximum moved.
+    // branch) whenever no lane's running maximum moved.  Accumulator element i of lane half h is
+    // key key0 + 16(i>>3) + 8h + (i&7) (see pi above).
     if (key0 + ATT_KT > T) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        int key = key0 + 16 * (i >> 3) + 8 * h + (i & 7);
         s_acc[i] = key < T ? s_acc[i] : -__builtin_inff();
       }
     }
@@ -558,20 +566,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint8_t* __restric
       pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
     }
     l_run += psum;
-    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8(j>>2) + 4h + (j&3)
+    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8h + j: chunk 2s + h of the hl32 row (lo: + 4)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int d = mt * 32 + r, sw = (d >> 1) & 15;
+      const int d = mt * 32 + r, sw = (d >> 1) & 7;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int g0 = 4 * s + h, g1 = g0 + 2;                 // 8-byte granules of the hi part (lo: +8)
-        half4 a0 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((g0 ^ sw) << 3));
-        half4 a1 = *reinterpret_cast<const half4*>(Vs + d * 128 + ((g1 ^ sw) << 3));
-        half4 b0 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g0 + 8) ^ sw) << 3));
-        half4 b1 = *reinterpret_cast<const half4*>(Vs + d * 128 + (((g1 + 8) ^ sw) << 3));
-        half8 vh, vl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+        const half8 vh = *reinterpret_cast<const half8*>(Vs + d * 128 + (((2 * s + h) ^ sw) << 4));
+        const half8 vl = *reinterpret_cast<const half8*>(Vs + d * 128 + (((2 * s + h + 4) ^ sw) << 4));
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[mt], 0, 0, 0);
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[mt], 0, 0, 0);
         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[mt], 0, 0, 0);
