@@ -29,7 +29,21 @@ static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi
   if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
   if (gemm_version() == 6) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
   if (gemm_version() == 7) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
-  if (gemm_version() != 3) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
+  if (gemm_version() != 3) {
+    // Small problems (a rank's shard of a category on 8 GPUs): when the 256x256 tiles would fill at most
+    // half the CUs, the 256x128 kernel does the same work in one round of half-size tiles
+    // (measured at 11 images: ViT block 0.71 -> 0.61 ms with the smaller tile, equal from 21 images up).
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    }
+    const long long tiles5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    if (gemm_version() == 8 && 2 * tiles5 > n_cu) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
+    if (gemm_version() != 8) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
+  }
   // start stagger of the first tile round, in units of 64 cycles per CU slot (see gemm_hl2.h)
   static int stagger = -1;
   if (stagger < 0) { const char* e = getenv("AC_STAGGER"); stagger = e ? atoi(e) : 0; }
