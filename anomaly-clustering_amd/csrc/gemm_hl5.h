@@ -20,10 +20,12 @@
 // and the stage density that would fix it costs more MFMA work than this kernel saves.)
 //
 // LDS (160 KB) = five 32 KB half-tiles: A in a 3-slot ring, B in a 2-slot ring, filled by
-// global_load_lds, 8 instructions per half-tile from each of the waves 0-3.  Per stage t two barriers:
-//   X(t), before the last row step: everybody's share of A(t+1), B(t+1) has landed; nobody reads A(t)
-//         any more                                          -> A(t+3) goes into A(t)'s slot (2 stages of cover)
-//   Y(t+1), after it: every wave holds B(t+1) in registers   -> B(t+3) goes into B(t+1)'s slot (1.75 stages)
+// global_load_lds, 8 instructions per half-tile from each of the waves 0-3.  ONE barrier per stage t,
+// X(t), before the last row step: everybody's share of A(t+1), B(t+1) has landed; nobody reads A(t) any
+// more and every wave took B(t) into registers a stage ago
+//   -> A(t+3) goes into A(t)'s slot (two stages of latency cover), B(t+2) into B(t)'s slot (one stage).
+// (A second barrier right after the B re-reads bought B 1.75 stages of cover but cost 3 %: the counter
+// waits are ~50 cycles per stage either way, the barrier is what is expensive - see DESIGN.md section 4.)
 #pragma once
 #include "gemm_hl2.h"
 
@@ -164,8 +166,7 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
   half8 ah = *reinterpret_cast<const half8*>(Aring + a_hi), al = *reinterpret_cast<const half8*>(Aring + a_lo);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  barrier();                                     // Y(0): B(0) is in registers everywhere
-  if (nk > 2) dmaB(2, 0);
+  barrier();                                     // B(0) is in registers everywhere: its slot may be refilled
   auto mfma3 = [&](f32x4& c, const half8& xh, const half8& xl, const half8& yh, const half8& yl) {
     if constexpr (SWAP) {
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, xh, c, 0, 0, 0);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
 
   int sa = 0;                                    // A slot of the current stage (kt % 3)
 #ifdef AC_TILE_TIMING
-  unsigned long long tx = 0, ty = 0, tx1 = 0, ty1 = 0, td = 0;
+  unsigned long long tx = 0, ty = 0, tx1 = 0, ty1 = 0, td = 0;   // (ty*: no second barrier any more)
   const unsigned long long tloop = __builtin_readcyclecounter();
 #endif
   auto stage = [&](int kt, auto steady) {
@@ -193,14 +194,15 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       if (mi == 3 && more1) {
-        // own share of A(kt+1), B(kt+1) landed: A(kt+2), B(kt+2) (8 each) may still fly
+        // own share of A(kt+1), B(kt+1) landed: A(kt+2) (8 instructions, the youngest) may still fly
         AC_T0();
-        if (more2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         AC_TACC(tx1);
         if (!(AC_ABLATE5 & 8)) barrier();        // X(kt)
         AC_TACC(tx);
+        if (more2 && !(AC_ABLATE5 & 1)) dmaB(kt + 2, kt & 1);   // B(kt) went to registers a stage ago
         if (more3 && !(AC_ABLATE5 & 1)) { AC_T0(); dmaA(kt + 3, sa); AC_TACC(td); }
       }
       half8 nh = ah, nl = al;
@@ -221,14 +223,6 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
         }
       }
       ah = nh; al = nl;
-    }
-    if (more1) {
-      AC_T0();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      AC_TACC(ty1);
-      if (!(AC_ABLATE5 & 8)) barrier();          // Y(kt+1)
-      AC_TACC(ty);
-      if (more3 && !(AC_ABLATE5 & 1)) dmaB(kt + 3, (kt + 1) & 1);
     }
     sa = sa1;
   };
