@@ -37,10 +37,14 @@ using gemm2::lptr_t;
 using gemm2::tile_off;
 using Frag = gemm::FragT<16>;
 
-constexpr int BM = 256, BN = 256, BK = 32, THREADS = 512;
-constexpr int HALF = 256 * 128;                 // one operand half-tile: 256 rows x 128 B
+constexpr int BM = 256, BK = 32, THREADS = 512;
+constexpr int HALF = 256 * 128;                 // the A half-tile: 256 rows x 128 B
 constexpr int A_SLOTS = 3, B_SLOTS = 2;
-constexpr int LDS_BYTES = (A_SLOTS + B_SLOTS) * HALF;   // 160 KB
+// NT = 16-column MFMA tiles per wave: 8 -> BN = 256 (the shape described above), 4 -> BN = 128 (64x64 per
+// wave; leaves room for the second accumulator of the two-level sum, FLUSH).
+constexpr int bn_of(int NT) { return NT * 32; }
+constexpr int lds_bytes(int NT) { return A_SLOTS * HALF + B_SLOTS * bn_of(NT) * 128; }   // 160 / 128 KB
+constexpr int FLUSH_STAGES = 16;
 
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE5=1 no DMA in the k loop, 2 no fragment
 // reads in the k loop, 4 no MFMAs, 8 no barriers in the k loop (combinable).  0 in every shipped build.
@@ -62,7 +66,7 @@ static __device__ unsigned long long ac_wait_times[8192 * 8];
 // run the upper triangle (tm <= tn) of the T x T tile matrix folded into a ceil(T/2) x (T+1) rectangle:
 // folded row p holds row p (T-p tiles) followed by row T-1-p (p+1 tiles).
 template <class Epi>
-__device__ inline bool tile_of(int id, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
+__device__ inline bool tile_of_square(int id, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
   gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {
@@ -77,7 +81,7 @@ __device__ inline bool tile_of(int id, int tiles_m, int tiles_n, int group_m, co
   return true;
 }
 
-template <class Epi>
+template <class Epi, int NT, bool FLUSH>
 __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
                                                      int id_lo, int id_hi, Epi epi) {
@@ -93,7 +97,10 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
 
   int tm = 0, tn = 0;
   const int id = id_lo + blockIdx.x;
-  if (id >= id_hi || !tile_of(id, tiles_m, tiles_n, group_m, epi, tm, tn)) return;   // block-uniform
+  constexpr int BN = bn_of(NT), HALF_B = BN * 128, NB = BN / 32;   // NB: B instructions per loader wave
+  if (id >= id_hi) return;
+  if constexpr (NT == 8) { if (!tile_of_square(id, tiles_m, tiles_n, group_m, epi, tm, tn)) return; }
+  else { if (!gemm2::tile_of(id, tiles_m, tiles_n, group_m, M, N, epi, tm, tn)) return; }   // block-uniform
   const int m0 = tm * BM, n0 = tn * BN;
 
   // DMA map: a half-tile is 32 wave-instructions of 1 KB (8 rows each).  Only waves 0-3 issue them
@@ -127,11 +134,11 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
     if (!loader) return;
     const uint8_t* base = B + (size_t)t * 128 + lc16;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const int row = row0 + 32 * j;
       const int brow = SWAP ? ((row & ~31) | (((row >> 2) & 3) << 3) | (((row >> 4) & 1) << 2) | (row & 3)) : row;
       const size_t off = (size_t)min(n0 + brow, N - 1) * ld;
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(Bring + slot * HALF + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(Bring + slot * HALF_B + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
     }
   };
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
@@ -139,28 +146,34 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   // fragment offsets: 16-row tile t of this wave's rows is base + t * 2048 bytes (the XOR swizzle term
   // (row >> 1) & 7 is unchanged by +16 rows)
   const int a_hi = tile_off(wm * 64 + (lane & 15), (lane >> 4)), a_lo = tile_off(wm * 64 + (lane & 15), 4 + (lane >> 4));
-  const int b_hi = tile_off(wn * 128 + (lane & 15), (lane >> 4)), b_lo = tile_off(wn * 128 + (lane & 15), 4 + (lane >> 4));
+  const int b_hi = tile_off(wn * (NT * 16) + (lane & 15), (lane >> 4)), b_lo = tile_off(wn * (NT * 16) + (lane & 15), 4 + (lane >> 4));
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][NT], tot[FLUSH ? 4 : 1][FLUSH ? NT : 1];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni)
+    for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[mi][ni][i] = 0.f;
+      for (int i = 0; i < 4; ++i) { acc[mi][ni][i] = 0.f; if constexpr (FLUSH) tot[mi][ni][i] = 0.f; }
 
   // prologue: A(0) B(0) A(1) B(1) A(2) in that order; the first two must have landed
   dmaA(0, 0);
   dmaB(0, 0);
   if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
   if (nk > 2) dmaA(2, 2);
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (NT == 8) {                       // leave A(1) B(1) A(2) = 8 + NB + 8 (or 8 + NB) in flight
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   barrier();
-  half8 bh[8], bl[8];
+  half8 bh[NT], bl[NT];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < NT; ++t) {
     bh[t] = *reinterpret_cast<const half8*>(Bring + b_hi + t * 2048);
     bl[t] = *reinterpret_cast<const half8*>(Bring + b_lo + t * 2048);
   }
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
     const int sa1 = sa == 2 ? 0 : sa + 1;        // (kt + 1) % 3
     const uint8_t* As = Aring + sa * HALF;
     const uint8_t* An = Aring + sa1 * HALF;
-    const uint8_t* Bn = Bring + ((kt + 1) & 1) * HALF;
+    const uint8_t* Bn = Bring + ((kt + 1) & 1) * HALF_B;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       if (mi == 3 && more1) {
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
         nl = *reinterpret_cast<const half8*>(An + a_lo);
       }
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) {
+      for (int ni = 0; ni < NT; ++ni) {
         if (!(AC_ABLATE5 & 4)) mfma3(acc[mi][ni], ah, al, bh[ni], bl[ni]);
         if (mi == 3 && more1 && !(AC_ABLATE5 & 2)) {
           bh[ni] = *reinterpret_cast<const half8*>(Bn + b_hi + ni * 2048);
@@ -224,12 +237,31 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
       }
       ah = nh; al = nl;
     }
+    // Two-level accumulation (gemm_hl.h): flush the MFMA accumulator every 512 k-terms.
+    if constexpr (FLUSH) {
+      if ((kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; }
+      }
+    }
     sa = sa1;
   };
   int kt = 0;
   for (; kt + 3 < nk; ++kt) stage(kt, std::true_type{});
   for (; kt < nk; ++kt) stage(kt, std::false_type{});
   barrier();                                     // ring reads done before an epilogue reuses LDS
+  if constexpr (FLUSH) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mi][ni][i] += tot[mi][ni][i];
+  }
 #ifdef AC_TILE_TIMING
   if ((tid == 0 || tid == 256) && blockIdx.x < 4096) {   // waves 0 and 4: the two waves of one SIMD
     unsigned long long* o = ac_wait_times + (blockIdx.x * 2 + (tid >> 8)) * 8;
@@ -238,23 +270,24 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
 #endif
 
-  // epilogue: the 64x128 accumulator as two 64x64 fragments of the common epilogue interface
+  // epilogue: the wave's 64 x (NT*16) accumulator as NT/4 64x64 fragments of the common epilogue interface
   const int m_wave = m0 + wm * 64;
 #pragma unroll
-  for (int no = 0; no < 2; ++no) {
+  for (int no = 0; no < NT / 4; ++no) {
     Frag f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) f.acc[mi][ni] = acc[mi][no * 4 + ni];
-    const int n_wave = n0 + wn * 128 + no * 64;
+    const int n_wave = n0 + wn * (NT * 16) + no * 64;
     if constexpr (SWAP) {
       epi.swapped(f, m_wave, n_wave, lane);
     } else if constexpr (EpiTraits<Epi>::kSymmetric) {
       if (epi.symmetric) {
-        // 64-row block rb against 64-column block cb of the symmetric matrix: rb < cb reduce both
-        // ways, rb == cb one way, rb > cb (lower part of a diagonal tile) is its mirror image's job
-        const int rb = tm * 4 + wm, cb = tn * 4 + wn * 2 + no;
+        // Row block rb against column block cb of the symmetric matrix: rb < cb reduce both ways,
+        // rb == cb one way, rb > cb (lower part of a diagonal tile) is its mirror image's job.
+        // NT == 8: 64-blocks of a square tile; NT == 4: 128-blocks of a 256x128 tile (gemm_hl2.h).
+        const int rb = NT == 8 ? tm * 4 + wm : 2 * tm + (wm >> 1), cb = NT == 8 ? tn * 4 + wn * 2 + no : tn;
         if (rb <= cb) epi(f, m_wave, n_wave, lane);
         if (rb < cb) epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65));
       } else {
@@ -266,33 +299,34 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
 }
 
-template <class Epi>
+template <class Epi, int NT = 8, bool FLUSH = false>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 4, int part = 0, int nparts = 1) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl5: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl5: bad part %d/%d", part, nparts);
+  constexpr int BN = bn_of(NT), LDS_BYTES = lds_bytes(NT);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   if constexpr (EpiTraits<Epi>::kSymmetric) {
-    if (epi.symmetric) {                           // folded upper triangle (see tile_of)
+    if (epi.symmetric) {                           // folded upper triangle (tile_of_square / gemm2::tile_of)
       if (M != N) return ac_fail(AC_EINVAL, "gemm_hl5: symmetric epilogue needs M == N");
-      const int T = tiles_m;
-      tiles_m = (T + 1) / 2;
-      tiles_n = T + 1;
+      const int Tm = tiles_m, Tn = tiles_n;
+      tiles_m = (Tm + 1) / 2;
+      tiles_n = NT == 8 ? Tm + 1 : 2 * Tn - 2 * Tm + 2;
     }
   }
   long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl5: grid too large");
   static bool attr_set = false;                    // per instantiation
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   long long lo = (total * part / nparts) & ~7LL;
   long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
-  hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
+  hipLaunchKernelGGL((kernel<Epi, NT, FLUSH>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
                      group_m, (int)lo, (int)hi, epi);
   return ac_check_launch("gemm_hl5");
