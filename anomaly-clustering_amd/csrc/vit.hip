@@ -110,8 +110,7 @@ struct EpiPatchEmbed {
 template <bool HL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, uint8_t* __restrict__ out_hl, float* __restrict__ out_f,
-                                                        int T = 0, int Tpad = 0) {
+                                                        float eps, uint8_t* __restrict__ out_hl, float* __restrict__ out_f) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -140,8 +139,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-  // optional padded output layout: token row b*T + t -> b*Tpad + t (pad rows are never written)
-  const int64_t orow = Tpad > 0 ? (row / T) * Tpad + row % T : row;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     int ch = lane + 64 * t;
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       float y[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = (v[t][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
-      if (HL) store_hl32_8(out_hl + (size_t)orow * C * 4, ch * 8, y);
+      if (HL) store_hl32_8(out_hl + (size_t)row * C * 4, ch * 8, y);
       else {
         *reinterpret_cast<f32x4*>(out_f + row * C + ch * 8) = *reinterpret_cast<f32x4*>(y);
         *reinterpret_cast<f32x4*>(out_f + row * C + ch * 8 + 4) = *reinterpret_cast<f32x4*>(y + 4);
@@ -258,9 +255,6 @@ template <> struct gemm::EpiTraits<EpiQK> { static constexpr bool kSymmetric = f
 // v, transposed: rows = v feature (head*64 + d) on the registers, cols = tokens on the lanes:
 // dest hl32 [B*H][64][Tpad] (K axis = token), so consecutive lanes write consecutive halves.
 struct EpiVt {
-  // Columns are PADDED token rows: n = b*Tpad + t (the LayerNorm in front writes that layout), so eight
-  // consecutive columns are eight consecutive tokens of one image, aligned to a 16-byte hl32 piece.
-  // Pad tokens t >= T are written as zeros (p = 0 there, but 0 * garbage must stay 0 in O^T += V^T P^T).
   const float* bias; uint8_t* vt; int C, NT, T, Tpad, H;   // bias already offset to the v third
   template <class F>
   __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
@@ -268,7 +262,7 @@ struct EpiVt {
     for (int ni = 0; ni < F::NT; ++ni) {
       const int col = n_wave + F::col(ni, lane);
       if (col >= NT) continue;
-      const int b = col / Tpad, t = col - b * Tpad;
+      const int b = col / T, t = col - b * T;
 #pragma unroll
       for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
@@ -276,39 +270,13 @@ struct EpiVt {
           int row = m_wave + F::row(mi, i, lane);
           if (row < C) {
             int head = row >> 6, d = row & 63;
-            float v = t < T ? f.acc[mi][ni][i] + bias[row] : 0.f;
+            float v = f.acc[mi][ni][i] + bias[row];
             _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
             uint8_t* p = vt + (((size_t)b * H + head) * HD + d) * ((size_t)Tpad * 4) + (t >> 5) * 128 + (t & 31) * 2;
             *reinterpret_cast<_Float16*>(p) = hi;
             *reinterpret_cast<_Float16*>(p + 64) = lo;
           }
         }
-    }
-  }
-  // swapped orientation (gemm_hl.h): the lane holds 8 consecutive tokens of one feature row
-  static constexpr bool kSwap = true;
-  template <class F>
-  __device__ void swapped(const F& f, int m_wave, int n_wave, int lane) const {
-    using S = gemm::SwapFrag;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int col = n_wave + S::col8(p, lane);
-      if (col >= NT) continue;
-      const int b = col / Tpad, t = col - b * Tpad;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int row = m_wave + S::row(mi, lane);
-        if (row >= C) continue;
-        const float bv = bias[row];
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = t + j < T ? f.acc[mi][2 * p][j] + bv : 0.f;
-          v[4 + j] = t + 4 + j < T ? f.acc[mi][2 * p + 1][j] + bv : 0.f;
-        }
-        const int head = row >> 6, d = row & 63;
-        store_hl32_8(vt + (((size_t)b * H + head) * HD + d) * ((size_t)Tpad * 4), t, v);
-      }
     }
   }
 };
@@ -654,6 +622,18 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   }
 }
 
+// zero the pad columns t in [T, Tpad) of every V^T row (p = 0 there, but 0 * garbage must stay 0)
+__global__ void zero_vt_pad_kernel(uint8_t* vt, int rows, int T, int Tpad) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int npad = Tpad - T;
+  if (i >= rows * npad) return;
+  int row = i / npad, t = T + (i - row * npad);
+  uint8_t* p = vt + (size_t)row * Tpad * 4 + (t >> 5) * 128 + (t & 31) * 2;
+  *reinterpret_cast<_Float16*>(p) = (_Float16)0.f;
+  *reinterpret_cast<_Float16*>(p + 64) = (_Float16)0.f;
+}
+
+// -------------------------------------------------------------------- C ABI
 struct VitWs {
   uint8_t *h, *q, *k, *vt, *o, *g, *cols;
 };
@@ -661,7 +641,7 @@ struct VitWs {
 static size_t vit_ws_carve(Arena& ar, int B, int T, int C, int hidden, int heads, int patch_dim, VitWs* w) {
   const size_t M = (size_t)B * T, Tp = tpad_of(T);
   VitWs t;
-  t.h = ar.take<uint8_t>((size_t)B * Tp * C * 4);   // LN1 writes token rows padded to Tp per image
+  t.h = ar.take<uint8_t>(M * C * 4);
   t.q = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
   t.k = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
   t.vt = ar.take<uint8_t>((size_t)B * heads * HD * Tp * 4);
@@ -729,16 +709,16 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
 
   // x_mid = x_in + proj(attn(ln1(x_in)))
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3(ln_grid), dim3(256), 0, stream, x_in, (int64_t)M, C, w->ln1_w, w->ln1_b,
-                     eps, b.h, (float*)nullptr, T, Tp);
-  // The q/k/v GEMMs run on the padded token rows (B*Tp): row b*Tp + t.  Pad rows of b.h hold whatever
-  // the buffer held before; they only reach pad rows of q and k (masked / never read by the attention
-  // kernel) and pad columns of v^T (written as zeros by the epilogue).
-  const int Mp = B * Tp;
+                     eps, b.h, (float*)nullptr);
   const uint8_t* wqkv = static_cast<const uint8_t*>(w->qkv_w);
-  EpiQK eqk{w->qkv_b, b.q, b.k, Mp, C, Tp, Tp, heads};
-  if ((rc = run_gemm(b.h, wqkv, Mp, 2 * C, C, eqk, stream))) return rc;
-  EpiVt evt{w->qkv_b + 2 * C, b.vt, C, Mp, T, Tp, heads};
-  if ((rc = run_gemm(wqkv + (size_t)2 * C * C * 4, b.h, C, Mp, C, evt, stream))) return rc;
+  EpiQK eqk{w->qkv_b, b.q, b.k, M, C, T, Tp, heads};
+  if ((rc = run_gemm(b.h, wqkv, M, 2 * C, C, eqk, stream))) return rc;
+  EpiVt evt{w->qkv_b + 2 * C, b.vt, C, M, T, Tp, heads};
+  if ((rc = run_gemm(wqkv + (size_t)2 * C * C * 4, b.h, C, M, C, evt, stream))) return rc;
+  if (Tp > T) {
+    int n = B * heads * HD * (Tp - T);
+    hipLaunchKernelGGL(zero_vt_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b.vt, B * heads * HD, T, Tp);
+  }
   hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.vt,
                      b.o, T, Tp, heads, 1.0f / sqrtf((float)HD));
   EpiResidual ep{w->proj_b, x_in, x_out, M, C};
