@@ -5,6 +5,7 @@
 #include "gemm_hl3.h"
 #include "gemm_hl4.h"
 #include "gemm_hl5.h"
+#include "gemm_hl6.h"
 #include <stdlib.h>
 
 // ------------------------------------------------------------------ packing
@@ -155,6 +156,7 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   // experimental loader-specialised kernel: single accumulation (timing studies)
   if (v == 6) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 7) return gemm4::launch<EpiPairMin, 1>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 11) return gemm6::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 9) return gemm5::launch<EpiPairMin, 4, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 8) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, gm > 0 ? gm : 4, part, nparts);
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);

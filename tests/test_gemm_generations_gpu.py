@@ -76,6 +76,7 @@ def test_all_pairs_two_level_variants_agree_bitwise(tmp_path):
     """The all-pairs kernel with two-level accumulation: 256x128 ring kernel (default) vs the gemm_hl5
     stream at 256x128 (AC_GEMM=9) - same flush schedule, same sums (D = 1024: two flushes)."""
     ref = _run(3, str(tmp_path / "a3.npz"))
-    got = _run(9, str(tmp_path / "a9.npz"))
-    for k in ("alpha_w_sym", "alpha_w_gen"):
-        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    for gen in (9, 11):                                # 11: the barrier-free (LDS counter) variant, gemm_hl6.h
+        got = _run(gen, str(tmp_path / ("a%d.npz" % gen)))
+        for k in ("alpha_w_sym", "alpha_w_gen"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="AC_GEMM=%d: %s" % (gen, k))
