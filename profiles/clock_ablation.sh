@@ -1,3 +1,5 @@
+# Average shader clock of the 256x256 GEMM, full kernel vs the -DAC_ABLATE5 timing builds (GRBM_GUI_ACTIVE / duration).
+# Needs build_ablate/libac5_ablate{1,11}.so; run with: gpurun -- bash profiles/clock_ablation.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for tag in full ab11 ab1; do

@@ -1,6 +1,7 @@
+# Run on the GPU box: gpurun -- bash profiles/collect.sh   (bench + rocprofv3 kernel stats + one --pmc pass per counter)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_final
+O=$R/gpurun_out/prof_final   # then: python profiles/summarize.py gpurun_out/prof_final/flat r01_bench "bottle:unsupervised:83:gpus1"
 rm -rf $O; mkdir -p $O
 python3 $R/bench.py --steps 5 --warmup 1 > $O/bench_plain.json 2>$O/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 1 > $O/bench_under_rocprof.json 2>$O/stats.err
