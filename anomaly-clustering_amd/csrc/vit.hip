@@ -696,6 +696,13 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
   AC_REQUIRE(heads > 0 && C == heads * HD, "ac_vit_block: C=%d must equal heads*64 (heads=%d)", C, heads);
   AC_REQUIRE(C % 32 == 0 && hidden % 32 == 0 && C <= 2048, "ac_vit_block: C, hidden must be multiples of 32; C <= 2048");
   AC_REQUIRE((long long)B * T < (1LL << 30), "ac_vit_block: too many tokens");
+  {
+    // the epilogues read biases / residual rows and write results with 16-byte accesses
+    const void* ptrs[] = {x_in, x_out, w->ln1_w, w->ln1_b, w->qkv_w, w->qkv_b, w->proj_w, w->proj_b,
+                          w->ln2_w, w->ln2_b, w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, ws};
+    for (const void* p : ptrs)
+      AC_REQUIRE(p && ((uintptr_t)p & 15) == 0, "ac_vit_block: every pointer must be non-null and 16-byte aligned");
+  }
   if (ws_bytes < ac_vit_workspace_bytes(B, T, C, hidden, heads, 32))
     return ac_fail(AC_EWORKSPACE, "ac_vit_block: workspace %zu < %zu", ws_bytes,
                    ac_vit_workspace_bytes(B, T, C, hidden, heads, 32));

@@ -15,6 +15,8 @@
  *     every buffer, including the scratch `ws` whose size the matching
  *     *_workspace_bytes() returns.  All pointers are DEVICE pointers unless a
  *     parameter says "host".
+ *   - every device pointer must be 16-byte aligned (the kernels use 16-byte loads
+ *     and stores); violations are reported as AC_EINVAL, not as a GPU fault.
  *   - returns AC_OK (0) or an AC_E* code; ac_last_error() gives the message of
  *     the calling thread's last failure.
  *   - "hl32" = the split-fp16 operand format of the MFMA kernels: a [rows, K]
