@@ -177,17 +177,19 @@ __device__ inline void store_hl32_line(uint8_t* line, const float* v) {
   }
 }
 
-// q,k: rows = tokens (b*T + t), cols in [0, 2C): dest hl32 [which][B*H][Tpad][64]
+// q, k, v: rows = tokens (b*T + t), cols in [0, 3C): dest hl32 [which][B*H][Tpad][64] (v in the same
+// token-major layout as k; the attention kernel reads it through transposing LDS reads)
 struct EpiQK {
-  const float* bias; uint8_t* q; uint8_t* k; int M, C, T, Tpad, H;
+  const float* bias; uint8_t* q; uint8_t* k; uint8_t* v; int M, C, T, Tpad, H;
+  __device__ uint8_t* dest(int which) const { return which == 0 ? q : which == 1 ? k : v; }
   template <class F>
   __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
 #pragma unroll
     for (int ni = 0; ni < F::NT; ++ni) {
       const int col = n_wave + F::col(ni, lane);
-      if (col >= 2 * C) continue;
+      if (col >= 3 * C) continue;
       const int which = col / C, fcol = col - which * C, head = fcol >> 6, d = fcol & 63;
-      uint8_t* base = (which ? k : q);
+      uint8_t* base = dest(which);
       const float bc = bias[col];
 #pragma unroll
       for (int mi = 0; mi < F::NT; ++mi)
@@ -212,12 +214,12 @@ struct EpiQK {
     for (int pass = 0; pass < 2; ++pass) {
       const int item = pass * 64 + lane, rl = item >> 1, half = item & 1;
       const int row = m_wave + rl, col0 = n_wave + half * 32;
-      if (row >= M || col0 >= 2 * C) continue;
+      if (row >= M || col0 >= 3 * C) continue;
       float v[32];
       load_staged_row(tl + rl * gemm::EPI_PITCH + half * 32, bias + col0, v);
       const int which = col0 / C, fcol = col0 - which * C, head = fcol >> 6, dh = (fcol & 63) >> 5;
       const int b = row / T, t = row - b * T;
-      store_hl32_line((which ? k : q) + (((size_t)b * H + head) * Tpad + t) * (HD * 4) + dh * 128, v);
+      store_hl32_line(dest(which) + (((size_t)b * H + head) * Tpad + t) * (HD * 4) + dh * 128, v);
     }
   }
   // swapped orientation (gemm_hl2.h): 8 consecutive columns of one token row per (mi, p)
@@ -235,9 +237,9 @@ struct EpiQK {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int col = n_wave + S::col8(p, lane);
-      if (col >= 2 * C) continue;
+      if (col >= 3 * C) continue;
       const int which = col / C, fcol = col - which * C, head = fcol >> 6, d = fcol & 63;
-      uint8_t* base = which ? k : q;
+      uint8_t* base = dest(which);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + col), b1 = *reinterpret_cast<const f32x4*>(bias + col + 4);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
@@ -251,35 +253,6 @@ struct EpiQK {
   }
 };
 template <> struct gemm::EpiTraits<EpiQK> { static constexpr bool kSymmetric = false; static constexpr bool kStaged = true; };
-
-// v, transposed: rows = v feature (head*64 + d) on the registers, cols = tokens on the lanes:
-// dest hl32 [B*H][64][Tpad] (K axis = token), so consecutive lanes write consecutive halves.
-struct EpiVt {
-  const float* bias; uint8_t* vt; int C, NT, T, Tpad, H;   // bias already offset to the v third
-  template <class F>
-  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
-#pragma unroll
-    for (int ni = 0; ni < F::NT; ++ni) {
-      const int col = n_wave + F::col(ni, lane);
-      if (col >= NT) continue;
-      const int b = col / T, t = col - b * T;
-#pragma unroll
-      for (int mi = 0; mi < F::NT; ++mi)
-#pragma unroll
-        for (int i = 0; i < F::NR; ++i) {
-          int row = m_wave + F::row(mi, i, lane);
-          if (row < C) {
-            int head = row >> 6, d = row & 63;
-            float v = f.acc[mi][ni][i] + bias[row];
-            _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
-            uint8_t* p = vt + (((size_t)b * H + head) * HD + d) * ((size_t)Tpad * 4) + (t >> 5) * 128 + (t & 31) * 2;
-            *reinterpret_cast<_Float16*>(p) = hi;
-            *reinterpret_cast<_Float16*>(p + 64) = lo;
-          }
-        }
-    }
-  }
-};
 
 // out[m][col] = acc + bias[col] + res[m][col]   (fp32; out may alias res)
 struct EpiResidual {
@@ -460,18 +433,22 @@ template <> struct gemm::EpiTraits<EpiGeluHl> { static constexpr bool kSymmetric
 // and the MFMA pipe sat at 31 %).
 // Key order: MFMA row rho of the S^T tile holds key pi(rho) = rho with bits 2 and 3 swapped.  The
 // accumulator-as-operand trick feeds P^T to the second product with k index j <-> accumulator row
-// 16s + 8(j>>2) + 4h + (j&3); with pi that row is key 16s + 8h + j, i.e. eight CONSECUTIVE keys per lane, so
-// a V^T fragment is one 16-byte read of the plain hl32 row (and the tile can be DMA'd as it lies in HBM).
+// 16s + 8(j>>2) + 4h + (j&3); with pi that row is key 16s + 8h + j, i.e. eight CONSECUTIVE keys per lane.
+// V stays token-major ([key][64 d] hl32 rows, written by the fused q/k/v GEMM like K - no transposed
+// GEMM, no V^T buffer): the V^T fragment of O^T += V^T P^T comes from ds_read_b64_tr_b16, which hands
+// lane i of a 16-lane group column i of a 4-key x 16-feature block, i.e. four consecutive keys of one
+// feature; two of them give the lane its eight keys.
 constexpr int ATT_Q = 128, ATT_KT = 32;
-constexpr int ATT_TILE = 16384;            // K tile [32 keys][256 B] + V^T tile [64 d][128 B]
+constexpr int ATT_TILE = 16384;            // K tile [32 keys][256 B] + V tile [32 keys][256 B]
 constexpr int ATT_LDS = 4 * 32 * 65 * 4;   // epilogue transpose buffer, >= the two tile buffers (32 KB)
 static_assert(ATT_LDS >= 2 * ATT_TILE, "tile double buffer must fit");
 
 __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ K,
-                                                        const uint8_t* __restrict__ Vt, uint8_t* __restrict__ O,
+                                                        const uint8_t* __restrict__ V, uint8_t* __restrict__ O,
                                                         int T, int Tpad, int H, float scale) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[ATT_LDS];
-  // per buffer: K tile, 16-byte slots XOR (row & 15); then V^T tile, 16-byte chunks XOR ((d >> 1) & 7)
+  __shared__ __attribute__((aligned(256))) uint8_t lds[ATT_LDS];
+  // per buffer: K tile, 16-byte slots XOR (row & 15); then V tile, 16-byte slots XOR ((row&3)<<2 | (row>>2)&3)
+  // (conflict-free for the transposed reads)
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
@@ -498,10 +475,10 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   const float c_log2 = scale * 1.44269504088896340736f;
 
   const uint8_t* Kbase = K + (size_t)bh * Tpad * (HD * 4);
-  const uint8_t* Vbase = Vt + (size_t)bh * HD * ((size_t)Tpad * 4);
+  const uint8_t* Vbase = V + (size_t)bh * Tpad * (HD * 4);
   const int ntiles = (T + ATT_KT - 1) / ATT_KT;
   // DMA map (1 KB per wave-instruction, lane l lands in 16-byte slot l of it; the swizzle goes on the
-  // SOURCE address).  K tile: instruction g = rows 4g..4g+3; V^T tile: instruction g = rows 8g..8g+7.
+  // SOURCE address).  K and V tiles: instruction g = key rows 4g..4g+3.
   // Wave w issues g = w and w + 4 of each.
   const uint8_t* ksrc[2];
   const uint8_t* vsrc[2];
@@ -510,8 +487,8 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     const int g = wave + 4 * j;
     const int krow = 4 * g + (lane >> 4), kslot = (lane & 15) ^ (krow & 15);
     ksrc[j] = Kbase + (size_t)krow * (HD * 4) + kslot * 16;
-    const int vrow = 8 * g + (lane >> 3), vchunk = (lane & 7) ^ ((vrow >> 1) & 7);
-    vsrc[j] = Vbase + (size_t)vrow * ((size_t)Tpad * 4) + vchunk * 16;
+    const int vslot = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+    vsrc[j] = Vbase + (size_t)krow * (HD * 4) + vslot * 16;
   }
   auto dma_tile = [&](int kt) {
     uint8_t* buf = lds + (kt & 1) * ATT_TILE;
@@ -519,10 +496,23 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     for (int j = 0; j < 2; ++j) {
       const int g = wave + 4 * j;
       __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[j] + (size_t)kt * (ATT_KT * HD * 4)), (lptr_t)(buf + g * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (size_t)kt * 128), (lptr_t)(buf + 8192 + g * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (size_t)kt * (ATT_KT * HD * 4)), (lptr_t)(buf + 8192 + g * 1024), 16, 0, 0);
     }
   };
   const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): key held by MFMA row r
+  // Transposed V reads.  16-lane group G = lane >> 4 serves features 16 (G&1) .. +15 of the 32-feature
+  // half mt and key half hk = G >> 1; lane 4q + p of the group addresses key row q of the 4-key block,
+  // features 4p .. 4p+3 (8 bytes).  For key block j2 (keys 16s + 8hk + 4 j2 + q) of feature half mt, plane
+  // hi/lo: byte = row*256 + ((ch ^ x) << 4) + 8 (p&1), ch = 8 mt + 4 plane + 2 (G&1) + (p>>1),
+  // x = (q << 2) | ((2 hk + j2) & 3).  mt and plane only flip address bits 7 and 6, s adds 4096.
+  const int trq = (lane & 15) >> 2, trp = lane & 3, trG = lane >> 4, trh = trG >> 1;
+  unsigned vaddr[2];
+#pragma unroll
+  for (int j2 = 0; j2 < 2; ++j2) {
+    const int row = 8 * trh + 4 * j2 + trq, ch = 2 * (trG & 1) + (trp >> 1), x = (trq << 2) | ((2 * trh + j2) & 3);
+    vaddr[j2] = (unsigned)(8192 + row * 256 + ((ch ^ x) << 4) + 8 * (trp & 1));
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
   dma_tile(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * ATT_KT;
@@ -580,18 +570,41 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
       pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
     }
     l_run += psum;
-    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8h + j: chunk 2s + h of the hl32 row (lo: + 4)
+    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8h + j, fetched as two transposed 4-key blocks
+    {
+      const unsigned vb0 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[0];
+      const unsigned vb1 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[1];
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      u32x2_t vr[2][2][2][2];              // [mt][s][plane][j2]
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int d = mt * 32 + r, sw = (d >> 1) & 7;
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const half8 vh = *reinterpret_cast<const half8*>(Vs + d * 128 + (((2 * s + h) ^ sw) << 4));
-        const half8 vl = *reinterpret_cast<const half8*>(Vs + d * 128 + (((2 * s + h + 4) ^ sw) << 4));
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[mt], 0, 0, 0);
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[mt], 0, 0, 0);
-        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[mt], 0, 0, 0);
-      }
+        for (int pn = 0; pn < 2; ++pn) {
+          const unsigned a0 = vb0 ^ (unsigned)(mt * 128 + pn * 64), a1 = vb1 ^ (unsigned)(mt * 128 + pn * 64);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[mt][0][pn][0]) : "v"(a0) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[mt][0][pn][1]) : "v"(a1) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vr[mt][1][pn][0]) : "v"(a0) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vr[mt][1][pn][1]) : "v"(a1) : "memory");
+        }
+      // The reads are asynchronous and the compiler does not know it: the wait must be a DEPENDENCY of
+      // every use of their results, or copies of the destination registers may be scheduled above it.
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vr[0][0][0][0]), "+v"(vr[0][0][0][1]), "+v"(vr[0][0][1][0]), "+v"(vr[0][0][1][1]),
+                     "+v"(vr[0][1][0][0]), "+v"(vr[0][1][0][1]), "+v"(vr[0][1][1][0]), "+v"(vr[0][1][1][1]),
+                     "+v"(vr[1][0][0][0]), "+v"(vr[1][0][0][1]), "+v"(vr[1][0][1][0]), "+v"(vr[1][0][1][1]),
+                     "+v"(vr[1][1][0][0]), "+v"(vr[1][1][0][1]), "+v"(vr[1][1][1][0]), "+v"(vr[1][1][1][1])
+                   :: "memory");
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u32x4 th = {vr[mt][s][0][0][0], vr[mt][s][0][0][1], vr[mt][s][0][1][0], vr[mt][s][0][1][1]};
+          u32x4 tl = {vr[mt][s][1][0][0], vr[mt][s][1][0][1], vr[mt][s][1][1][0], vr[mt][s][1][1][1]};
+          const half8 vh = __builtin_bit_cast(half8, th), vl = __builtin_bit_cast(half8, tl);
+          o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[mt], 0, 0, 0);
+          o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[mt], 0, 0, 0);
+          o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[mt], 0, 0, 0);
+        }
     }
   }
   // normalise, transpose through LDS ([32 q][65] floats per wave), write hl32 lines
@@ -622,20 +635,18 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   }
 }
 
-// zero the pad columns t in [T, Tpad) of every V^T row (p = 0 there, but 0 * garbage must stay 0)
-__global__ void zero_vt_pad_kernel(uint8_t* vt, int rows, int T, int Tpad) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  int npad = Tpad - T;
-  if (i >= rows * npad) return;
-  int row = i / npad, t = T + (i - row * npad);
-  uint8_t* p = vt + (size_t)row * Tpad * 4 + (t >> 5) * 128 + (t & 31) * 2;
-  *reinterpret_cast<_Float16*>(p) = (_Float16)0.f;
-  *reinterpret_cast<_Float16*>(p + 64) = (_Float16)0.f;
+// zero the pad rows t in [T, Tpad) of every V image (p = 0 there, but 0 * garbage must stay 0)
+__global__ void zero_v_pad_kernel(uint8_t* v, int images, int T, int Tpad) {
+  const int per = (Tpad - T) * (HD * 4) / 16;           // 16-byte pieces per image
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= images * per) return;
+  const int img = i / per, piece = i - img * per;
+  u32x4 z = {0u, 0u, 0u, 0u};
+  *reinterpret_cast<u32x4*>(v + ((size_t)img * Tpad + T) * (HD * 4) + (size_t)piece * 16) = z;
 }
 
-// -------------------------------------------------------------------- C ABI
 struct VitWs {
-  uint8_t *h, *q, *k, *vt, *o, *g, *cols;
+  uint8_t *h, *q, *k, *v, *o, *g, *cols;
 };
 
 static size_t vit_ws_carve(Arena& ar, int B, int T, int C, int hidden, int heads, int patch_dim, VitWs* w) {
@@ -644,7 +655,7 @@ static size_t vit_ws_carve(Arena& ar, int B, int T, int C, int hidden, int heads
   t.h = ar.take<uint8_t>(M * C * 4);
   t.q = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
   t.k = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
-  t.vt = ar.take<uint8_t>((size_t)B * heads * HD * Tp * 4);
+  t.v = ar.take<uint8_t>((size_t)B * heads * Tp * HD * 4);
   t.o = ar.take<uint8_t>(M * C * 4);
   t.g = ar.take<uint8_t>(M * (size_t)hidden * 4);
   t.cols = ar.take<uint8_t>(M * (size_t)patch_dim * 4);
@@ -718,15 +729,13 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3(ln_grid), dim3(256), 0, stream, x_in, (int64_t)M, C, w->ln1_w, w->ln1_b,
                      eps, b.h, (float*)nullptr);
   const uint8_t* wqkv = static_cast<const uint8_t*>(w->qkv_w);
-  EpiQK eqk{w->qkv_b, b.q, b.k, M, C, T, Tp, heads};
-  if ((rc = run_gemm(b.h, wqkv, M, 2 * C, C, eqk, stream))) return rc;
-  EpiVt evt{w->qkv_b + 2 * C, b.vt, C, M, T, Tp, heads};
-  if ((rc = run_gemm(wqkv + (size_t)2 * C * C * 4, b.h, C, M, C, evt, stream))) return rc;
+  EpiQK eqkv{w->qkv_b, b.q, b.k, b.v, M, C, T, Tp, heads};
+  if ((rc = run_gemm(b.h, wqkv, M, 3 * C, C, eqkv, stream))) return rc;
   if (Tp > T) {
-    int n = B * heads * HD * (Tp - T);
-    hipLaunchKernelGGL(zero_vt_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b.vt, B * heads * HD, T, Tp);
+    const int n = B * heads * (Tp - T) * (HD * 4) / 16;
+    hipLaunchKernelGGL(zero_v_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b.v, B * heads, T, Tp);
   }
-  hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.vt,
+  hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.v,
                      b.o, T, Tp, heads, 1.0f / sqrtf((float)HD));
   EpiResidual ep{w->proj_b, x_in, x_out, M, C};
   if ((rc = run_gemm(b.o, w->proj_w, M, C, C, ep, stream))) return rc;
