@@ -522,6 +522,24 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     __syncthreads();                                   // ... everybody's has; tile kt-1 is fully consumed
     if (kt + 1 < ntiles) dma_tile(kt + 1);             // flies under this tile's MFMAs
 
+    // V^T fragments: two transposed 4-key blocks per (feature half, key group, plane), issued now so that
+    // their latency hides under the S^T MFMAs and the softmax
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t vr[2][2][2][2];              // [mt][s][plane][j2]
+    {
+      const unsigned vb0 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[0];
+      const unsigned vb1 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[1];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int pn = 0; pn < 2; ++pn) {
+          const unsigned a0 = vb0 ^ (unsigned)(mt * 128 + pn * 64), a1 = vb1 ^ (unsigned)(mt * 128 + pn * 64);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[mt][0][pn][0]) : "v"(a0) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[mt][0][pn][1]) : "v"(a1) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vr[mt][1][pn][0]) : "v"(a0) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vr[mt][1][pn][1]) : "v"(a1) : "memory");
+        }
+    }
     // S^T tile [32 keys x 32 queries]
     f32x16 s_acc;
 #pragma unroll
@@ -570,22 +588,8 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
       pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
     }
     l_run += psum;
-    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8h + j, fetched as two transposed 4-key blocks
+    // O^T += V^T P^T ; A fragment element j <-> key 16s + 8h + j (the transposed reads were issued above)
     {
-      const unsigned vb0 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[0];
-      const unsigned vb1 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[1];
-      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-      u32x2_t vr[2][2][2][2];              // [mt][s][plane][j2]
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int pn = 0; pn < 2; ++pn) {
-          const unsigned a0 = vb0 ^ (unsigned)(mt * 128 + pn * 64), a1 = vb1 ^ (unsigned)(mt * 128 + pn * 64);
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[mt][0][pn][0]) : "v"(a0) : "memory");
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vr[mt][0][pn][1]) : "v"(a1) : "memory");
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vr[mt][1][pn][0]) : "v"(a0) : "memory");
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(vr[mt][1][pn][1]) : "v"(a1) : "memory");
-        }
       // The reads are asynchronous and the compiler does not know it: the wait must be a DEPENDENCY of
       // every use of their results, or copies of the destination registers may be scheduled above it.
       asm volatile("s_waitcnt lgkmcnt(0)"
