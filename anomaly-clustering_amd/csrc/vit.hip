@@ -517,7 +517,6 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * ATT_KT;
     const uint8_t* Ks = lds + (kt & 1) * ATT_TILE;
-    const uint8_t* Vs = Ks + 8192;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile kt has landed
     __syncthreads();                                   // ... everybody's has; tile kt-1 is fully consumed
     if (kt + 1 < ntiles) dma_tile(kt + 1);             // flies under this tile's MFMAs
