@@ -427,7 +427,7 @@ template <> struct gemm::EpiTraits<EpiGeluHl> { static constexpr bool kSymmetric
 // the lane, so the softmax max/sum over keys are in-lane reductions plus one lane-half exchange,
 // and the exponentiated tile is already laid out as the B operand of O^T += V^T P^T
 // (accumulator-as-operand, k order 16s + 8(j>>2) + 4h + (j&3); V^T fragments are read in that order).
-// Block = 4 waves x 32 queries.  K and V^T tiles of 32 keys go global -> LDS by global_load_lds into a
+// Block = 4 waves x 32 queries.  K and V tiles of 32 keys go global -> LDS by global_load_lds into a
 // double buffer, one tile ahead of the MFMAs (no staging registers: a register double buffer cost a wave
 // of occupancy and ran slower; without any prefetch the ~1.5 us load latency of every tile was exposed
 // and the MFMA pipe sat at 31 %).
