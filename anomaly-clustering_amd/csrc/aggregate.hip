@@ -14,9 +14,12 @@
 // are re-read from L2 (each token is needed by k*k neighbouring patches).
 #include "common.h"
 
-// ---- pass 1: per (layer, image) sum and sum of squares over C*H*W values, fp64
+// ---- pass 1: per (layer, image) sum and sum of squares over C*H*W values, fp64.  Deterministic: every
+// workgroup writes its partial pair to its own slot, agg_stats_finish_kernel adds the slots in a fixed order
+// (mean and rstd scale every value of Z, so a run-to-run last-bit difference here would show everywhere).
+constexpr int kStatChunks = 64;
 __global__ __launch_bounds__(256) void agg_stats_kernel(const float* __restrict__ f, int kind, int C, int HW,
-                                                        double* __restrict__ stats /* [B][2] */) {
+                                                        double* __restrict__ partial /* [B][kStatChunks][2] */) {
   const int b = blockIdx.y;
   // both kinds: the image's values are one contiguous range (tokens: after the CLS row)
   const size_t n = (size_t)C * HW;
@@ -34,9 +37,21 @@ __global__ __launch_bounds__(256) void agg_stats_kernel(const float* __restrict_
   if (lane == 0) { red[0][wv] = s; red[1][wv] = ss; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&stats[b * 2 + 0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-    atomicAdd(&stats[b * 2 + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    double* o = partial + ((size_t)b * kStatChunks + blockIdx.x) * 2;
+    o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
+}
+
+// one wave per image: lane c holds chunk c's partial, fixed-order butterfly
+__global__ __launch_bounds__(64) void agg_stats_finish_kernel(const double* __restrict__ partial, int chunks,
+                                                              double* __restrict__ stats /* [B][2] */) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const double* p = partial + ((size_t)b * kStatChunks + lane) * 2;
+  double s = lane < chunks ? p[0] : 0.0, ss = lane < chunks ? p[1] : 0.0;
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane == 0) { stats[b * 2] = s; stats[b * 2 + 1] = ss; }
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs, and neighbouring patches share 6 of their 9 tokens:
@@ -236,7 +251,8 @@ extern "C" size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C,
                                                      int patchsize, int pre_dim, int tgt_dim) {
   (void)C; (void)H; (void)W; (void)patchsize; (void)pre_dim; (void)tgt_dim;
   if (n_layers <= 0 || B <= 0) return 256;
-  return align_up((size_t)n_layers * B * 2 * sizeof(double), 256) + 256;
+  return align_up((size_t)n_layers * B * 2 * sizeof(double), 256) +
+         align_up((size_t)n_layers * B * kStatChunks * 2 * sizeof(double), 256) + 256;
 }
 
 extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, const int* C, const int* H, const int* W,
@@ -255,7 +271,7 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
   prm.n_layers = n_layers; prm.k = patchsize; prm.pre = pre_dim; prm.tgt = tgt_dim;
   prm.H0 = H[0]; prm.W0 = W[0]; prm.eps = eps; prm.Z = Z;
   double* stats = static_cast<double*>(ws);
-  (void)hipMemsetAsync(stats, 0, (size_t)n_layers * B * 2 * sizeof(double), stream);
+  double* partial = stats + align_up((size_t)n_layers * B * 2 * sizeof(double), 256) / sizeof(double);
   int maxL = 0;
   for (int l = 0; l < n_layers; ++l) {
     AC_REQUIRE(feats[l] && C[l] > 0 && H[l] > 0 && W[l] > 0, "ac_patch_aggregate: bad layer %d", l);
@@ -264,9 +280,11 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
     maxL = maxL > C[l] * patchsize * patchsize ? maxL : C[l] * patchsize * patchsize;
     size_t n = (size_t)C[l] * H[l] * W[l];
     int chunks = (int)((n + 256 * 16 - 1) / (256 * 16));
-    if (chunks > 64) chunks = 64;
+    if (chunks > kStatChunks) chunks = kStatChunks;
+    double* part_l = partial + (size_t)l * B * kStatChunks * 2;
     hipLaunchKernelGGL(agg_stats_kernel, dim3(chunks, B), dim3(256), 0, stream, feats[l], kind[l], C[l], H[l] * W[l],
-                       stats + (size_t)l * B * 2);
+                       part_l);
+    hipLaunchKernelGGL(agg_stats_finish_kernel, dim3(B), dim3(64), 0, stream, part_l, chunks, stats + (size_t)l * B * 2);
   }
   AC_REQUIRE((long long)(pre_dim + 1) * maxL < (1LL << 31) && (long long)(tgt_dim + 1) * n_layers * pre_dim < (1LL << 31),
              "ac_patch_aggregate: pooling index arithmetic would overflow 32 bits");
@@ -282,12 +300,10 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
     size_t flds = ((size_t)patchsize * patchsize * (maxC + 4) + (identity ? 0 : (size_t)n_layers * pre_dim)) * sizeof(float);
     if (flds <= 160 * 1024) {
       if (patchsize == 3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_pool_tokens_kernel<3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&agg_pool_tokens_kernel<3>), (int)flds, nullptr)) return rc;
         hipLaunchKernelGGL(agg_pool_tokens_kernel<3>, dim3(H[0] * W[0], B), dim3(256), flds, stream, prm);
       } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_pool_tokens_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&agg_pool_tokens_kernel<1>), (int)flds, nullptr)) return rc;
         hipLaunchKernelGGL(agg_pool_tokens_kernel<1>, dim3(H[0] * W[0], B), dim3(256), flds, stream, prm);
       }
       return ac_check_launch("ac_patch_aggregate(tokens)");
@@ -295,8 +311,7 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
   }
   size_t lds = ((size_t)maxL + (size_t)n_layers * pre_dim) * sizeof(float);
   AC_REQUIRE(lds <= 160 * 1024, "ac_patch_aggregate: C*k*k + layers*pre_dim = %zu floats exceeds LDS", lds / 4);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&agg_pool_kernel), (int)lds, nullptr)) return rc;
   hipLaunchKernelGGL(agg_pool_kernel, dim3(H[0] * W[0], B), dim3(256), lds, stream, prm);
   return ac_check_launch("ac_patch_aggregate");
 }

@@ -2,11 +2,14 @@
 // fp64 softmax, weighted-average embedding, condensed pdist.
 // Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
 // scipy pdist under examples/test.py:193-195.
-#include "gemm_hl3.h"
-#include "gemm_hl4.h"
+#include "gemm_hl2.h"
+#ifdef AC_EXPERIMENTAL
 #include "gemm_hl5.h"
-#include "gemm_hl6.h"
-#include <stdlib.h>
+#include "experimental/gemm_hl1.h"
+#include "experimental/gemm_hl3.h"
+#include "experimental/gemm_hl4.h"
+#include "experimental/gemm_hl6.h"
+#endif
 
 // ------------------------------------------------------------------ packing
 // fp32 [rows, K] -> hl32 + optional squared row norms.  One wave per row; each lane
@@ -138,27 +141,25 @@ struct EpiPairMin {
 };
 template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; static constexpr bool kStaged = false; };
 
-// general (non-symmetric) launches use the LDS-DMA ring kernel unless AC_GEMM=1
+// The all-pairs kernel is gemm_hl2.h's 256x128 ring kernel with two-level accumulation (FLUSH): the only tile
+// whose per-wave state leaves room for the second accumulator that fp32-grade distances need (DESIGN.md
+// section 2; the 256x256 stream without it is 10 % faster and 6x further from the fp64 truth).
+// L2 window of the rasterisation (tile rows per group): in the folded symmetric grid tile (p, c) is
+// (tm, tn) = (p, 2p + c), so a window of R rows x C columns touches R row panels but 2R - 2 + C column
+// panels and a flat window re-reads least (FETCH_SIZE confirmed: 4 rows -28 % L2-miss bytes vs 8).
 static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream,
                            int part = 0, int nparts = 1) {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 3; }
-  if (v == 1 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
-  // experimental 256x256 kernel: general (non-symmetric) problems only, single accumulation (timing studies)
-  if (v == 5 && nparts == 1 && !epi.symmetric) return gemm3::launch(A, B, M, N, K, epi, stream, 4);
-  // L2 window of the rasterisation (tile rows per group).  In the folded symmetric grid tile (p, c) is
-  // (tm, tn) = (p, 2p + c): a window of P rows x C columns touches P row panels but 2P - 2 + C column
-  // panels, so a flat window (few rows, many columns) re-reads least: 11 KB per tile-stage at 4 x 8 vs
-  // 17 KB at 8 x 4 (FETCH_SIZE confirmed the 8-row window at a 67 % L2 hit rate).
-  static int gm = -1;
-  if (gm < 0) { const char* e = getenv("AC_GROUPM"); gm = e ? atoi(e) : 0; }
-  const int group_m = gm > 0 ? gm : (epi.symmetric ? 4 : 8);
-  // experimental loader-specialised kernel: single accumulation (timing studies)
-  if (v == 6) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
-  if (v == 7) return gemm4::launch<EpiPairMin, 1>(A, B, M, N, K, epi, stream, group_m, part, nparts);
-  if (v == 11) return gemm6::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
-  if (v == 9) return gemm5::launch<EpiPairMin, 4, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
-  if (v == 8) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, gm > 0 ? gm : 4, part, nparts);
+  const int group_m = epi.symmetric ? 4 : 8;
+#ifdef AC_EXPERIMENTAL
+  const int v = ac_gemm_policy();
+  if (v == 101 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
+  if (v == 103 && nparts == 1 && !epi.symmetric) return gemm3::launch(A, B, M, N, K, epi, stream, 4);
+  if (v == 104) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 105) return gemm4::launch<EpiPairMin, 1>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 106) return gemm6::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 109) return gemm5::launch<EpiPairMin, 4, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 108) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, 4, part, nparts);   // single accumulation
+#endif
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
 }
 

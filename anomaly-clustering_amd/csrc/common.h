@@ -17,6 +17,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 int ac_fail(int code, const char* fmt, ...);
 int ac_check_launch(const char* what);
 
+int ac_device_cus();                 // CU count of the calling thread's current device (cached per device)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device); done_mask is the
+// instantiation's own static word (bit = device id).
+int ac_set_max_lds(const void* kernel, int bytes, unsigned long long* done_mask);
+int ac_gemm_policy();                // AC_GEMM_* (ac_set_gemm_policy)
+
 #define AC_REQUIRE(cond, ...) do { if (!(cond)) return ac_fail(AC_EINVAL, __VA_ARGS__); } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

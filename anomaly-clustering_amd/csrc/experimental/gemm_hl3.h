@@ -1,4 +1,4 @@
-// Split-fp16 MFMA GEMM, third generation (EXPERIMENTAL, selected with AC_GEMM=5): 256x256x32 tiles,
+// Split-fp16 MFMA GEMM, third generation (EXPERIMENTAL, ac_set_gemm_policy 103 in -DAC_EXPERIMENTAL builds): 256x256x32 tiles,
 // 4 waves, ONE wave per SIMD with the whole 512-register file.
 //
 // gemm_hl2.h is co-limited by operand delivery (18.4 ms of global->LDS traffic
@@ -19,7 +19,7 @@
 //   * 2 LDS-DMA instructions per step: steps 7,0,1,2 fetch B(t+2 | t+1), steps 3..6 fetch A(t+2).
 // LDS (160 KB): A in a 3-slot ring (two stages of latency cover), B in a 2-slot ring (one stage).
 #pragma once
-#include "gemm_hl2.h"
+#include "../gemm_hl2.h"
 
 namespace gemm3 {
 

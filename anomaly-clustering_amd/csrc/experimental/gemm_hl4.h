@@ -1,4 +1,4 @@
-// Split-fp16 MFMA GEMM, loader-specialised variants of gemm_hl2.h (EXPERIMENTAL, AC_GEMM=6 / 7).
+// Split-fp16 MFMA GEMM, loader-specialised variants of gemm_hl2.h (EXPERIMENTAL, ac_set_gemm_policy 104 / 105).
 //
 // Same 256x128x32 tile and LDS-DMA ring as gemm_hl2.h, but the global->LDS traffic is issued by four
 // dedicated LOADER waves (one per SIMD) instead of by the eight MFMA waves.  Ablation of gemm_hl2.h
@@ -8,13 +8,13 @@
 // (~1100 cycles) against 1536 MFMA cycles.  Three waves per SIMD leave 168 registers per wave, so
 // there is no second accumulator here (single-level accumulation only).
 //
-// MODE 0 (AC_GEMM=6): the staggered two-group schedule of gemm_hl2.h, two barriers per stage.
-// MODE 1 (AC_GEMM=7): every MFMA wave runs one continuous stream - the fragments of stage t+1 are read
+// MODE 0 (policy 104): the staggered two-group schedule of gemm_hl2.h, two barriers per stage.
+// MODE 1 (policy 105): every MFMA wave runs one continuous stream - the fragments of stage t+1 are read
 //   from LDS while the MFMAs of stage t run, each into registers whose stage-t value has just had its
 //   last use (A row fragments after their row; B fragments in the last row), plus 24 spare registers for
 //   the three fragments that die too late.  One barrier per stage.
 #pragma once
-#include "gemm_hl2.h"
+#include "../gemm_hl2.h"
 
 namespace gemm4 {
 

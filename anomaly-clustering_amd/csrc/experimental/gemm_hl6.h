@@ -1,5 +1,5 @@
 // Split-fp16 MFMA GEMM, 256x128x32 tiles, 8 waves, NO block-wide barrier in the k loop (EXPERIMENTAL,
-// AC_GEMM=11 for the all-pairs kernel).
+// ac_set_gemm_policy 106 for the all-pairs kernel, -DAC_EXPERIMENTAL builds).
 //
 // Why: the wait-time stamps of gemm_hl5.h show what a barrier costs here.  The two
 // waves of a SIMD share the MFMA pipe and the arbiter serves the older one first; it reaches the barrier
@@ -22,7 +22,7 @@
 // accumulation (FLUSH), symmetric / swapped epilogues.  All spins are bounded: a protocol error gives
 // wrong numbers, not a hung GPU.
 #pragma once
-#include "gemm_hl5.h"
+#include "../gemm_hl5.h"
 
 namespace gemm6 {
 

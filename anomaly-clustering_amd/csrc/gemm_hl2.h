@@ -26,7 +26,7 @@
 //   * PERSISTENT: the grid is one workgroup per CU; each walks tiles id, id+grid, ...  The first two
 //     stages of the NEXT tile are issued before the epilogue of the current one, so the epilogue and the
 //     DMA latency of the next tile's prologue overlap (K = 768 GEMMs spent ~30 % of their time there).
-// Measured (MI355X, K = 4096 all-pairs): 66 % MFMA-pipe utilisation at the 1.5-1.6 GHz the chip
+// Measured (MI355X, K = 4096 all-pairs): 66 % MFMA-pipe utilisation at the 1.72-1.81 GHz the chip
 // sustains under this load; LDS-DMA vs register staging and block-issue vs interleaved DMA issue were
 // all within 2 % of each other (profiles/).
 #pragma once
@@ -100,17 +100,9 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   const int wm = wave >> 1, wn = wave & 1;
   const bool groupB = wave >= 4;
   constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
-  // De-synchronise the CUs.  Equal tiles keep all 256 CUs in lockstep, so every round ends in one burst
-  // of epilogue traffic (256 KB per CU at once) during which no MFMA runs anywhere.  The first block of
-  // each CU (blockIdx < 256; blocks go round-robin over the 8 XCDs, so (blockIdx >> 3) & 31 is the CU
-  // slot within its XCD) starts `stagger` x slot x 64 cycles late; the offsets persist from tile to tile
-  // and the bursts turn into a steady background stream.
-#ifndef AC_TILE_TIMING
-  if (stagger > 0 && blockIdx.x < 256) {
-    const int n = stagger * ((blockIdx.x >> 3) & 31);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
+  // (`stagger`: launch slot of the -DAC_TILE_TIMING stamps.  A start stagger of the first tile round across
+  // the CUs, meant to turn the lockstep epilogue bursts into a steady stream, measured -1...-6 %: removed.)
+  (void)stagger;
   AC_STAMP(0);
   const size_t ld = (size_t)K * 4;
   const int nk = K / BK;
@@ -300,7 +292,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 // all-pairs problem over several GPUs.
 template <class Epi, bool FLUSH = false>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                  int group_m = 8, int part = 0, int nparts = 1, int stagger = 0) {
+                  int group_m = 8, int part = 0, int nparts = 1, bool persistent = false) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl2: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl2: bad part %d/%d", part, nparts);
@@ -315,31 +307,18 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   }
   long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl2: grid too large");
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return ac_fail(AC_ELAUNCH, "gemm_hl2: cannot query the device");
-    n_cu = prop.multiProcessorCount;
-  }
-  static bool attr_set = false;                    // per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi, FLUSH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;       // per instantiation, one bit per device
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, FLUSH>), LDS_BYTES, &attr_done)) return rc;
   long long lo = (total * part / nparts) & ~7LL;
   long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
-  // One workgroup per tile by default.  AC_PERSIST=1 launches one persistent workgroup per CU instead
-  // (the kernel supports both); same-box A/B: equal within noise on the K = 768 ViT GEMMs, 4 % slower on
-  // the general K = 4096 all-pairs kernel - the static tile walk loses at the tail what the overlapped
-  // prologue gains, so the hardware dispatcher keeps the job.
-  static int persist = -1;
-  if (persist < 0) { const char* e = getenv("AC_PERSIST"); persist = (e && e[0] == '1') ? 1 : 0; }
-  long long grid = (persist && hi - lo > n_cu) ? n_cu : hi - lo;
-  int stagger_arg = (hi - lo > 2 * n_cu && !persist) ? stagger : 0;
+  // One workgroup per tile.  (The kernel can also walk tiles persistently, one workgroup per CU with the
+  // next tile's first stages issued under the epilogue: same-box A/B equal within noise on the K = 768 ViT
+  // GEMMs, 4 % slower on the K = 4096 all-pairs kernel - the static walk loses at the tail what the
+  // overlapped prologue gains - so the hardware dispatcher keeps the job; `persistent` is for A/B runs.)
+  const int n_cu = ac_device_cus();
+  long long grid = (persistent && hi - lo > n_cu) ? n_cu : hi - lo;
+  int stagger_arg = 0;
 #ifdef AC_TILE_TIMING
   stagger_arg = tt_counter()++ & 7;
 #endif

@@ -1,4 +1,4 @@
-// Split-fp16 MFMA GEMM, 256x256x32 tiles on 8 waves (2 per SIMD)  -  AC_GEMM=8.
+// Split-fp16 MFMA GEMM, 256x256x32 tiles on 8 waves (2 per SIMD).
 //
 // Why: tile-phase timing of gemm_hl2.h (tests/tile_timing.py) shows its k loop runs
 // at 1.25-1.5 us per stage where the MFMAs need 0.85: with a 3-slot ring only two 48 KB stages are in
@@ -317,12 +317,8 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   }
   long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl5: grid too large");
-  static bool attr_set = false;                    // per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  static unsigned long long attr_done = 0;       // per instantiation, one bit per device
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH>), LDS_BYTES, &attr_done)) return rc;
   long long lo = (total * part / nparts) & ~7LL;
   long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;

@@ -3,51 +3,38 @@
 // prepare_tokens :196-207, Attention :80-92, Mlp :59-65, Block :107-113; eps 1e-6 from :253).
 //
 // Every dense contraction (patch projection, qkv, QK^T, PV, proj, fc1, fc2) runs on
-// v_mfma_f32_32x32x16_f16 in the 3-pass split-fp16 scheme (gemm_hl.h), so the result is
+// v_mfma_f32_16x16x32_f16 in the 3-pass split-fp16 scheme (gemm_hl.h), so the result is
 // fp32-grade like the reference's fp32 CPU path.  The residual stream x stays fp32 in HBM;
 // everything that feeds an MFMA (LN output, q/k/v, attention output, GELU output) is written
 // directly in hl32 form by the producing kernel's epilogue - same bytes as fp32, no
 // conversion pass.
-#include "gemm_hl3.h"
-#include "gemm_hl4.h"
 #include "gemm_hl5.h"
-#include <stdlib.h>
+#ifdef AC_EXPERIMENTAL
+#include "experimental/gemm_hl1.h"
+#include "experimental/gemm_hl3.h"
+#include "experimental/gemm_hl4.h"
+#endif
 
 constexpr int HD = 64;          // head dim (all DINO ViTs)
 
-// Default: the 256x256 kernel (gemm_hl5.h).  AC_GEMM selects another generation for same-box A/B runs:
-// 1 = 128x128 register staged (gemm_hl.h), 3 = 256x128 LDS-DMA ring (gemm_hl2.h), 5 = 256x256 on 4 waves
-// (gemm_hl3.h), 6 / 7 = loader-specialised 256x128 (gemm_hl4.h), 8 = gemm_hl5.h.
-static int gemm_version() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("AC_GEMM"); v = e ? atoi(e) : 8; }
-  return v;
-}
+// Linear layers: the 256x256 kernel (gemm_hl5.h), or - for small problems, e.g. a rank's shard of a category
+// on 8 GPUs - the 256x128 kernel (gemm_hl2.h): when the 256x256 tiles would fill at most half the CUs, half-size
+// tiles do the same work in one round (measured at 11 images: ViT block 0.71 -> 0.61 ms, equal from 21 images up).
+// The two kernels give bit-identical results (tests/test_gemm_generations_gpu.py); ac_set_gemm_policy() pins
+// one of them for that test and for same-box A/B timing.
 template <class Epi>
 static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream) {
-  if (gemm_version() == 1) return gemm::launch(A, B, M, N, K, epi, stream);
-  if (gemm_version() == 5) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
-  if (gemm_version() == 6) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
-  if (gemm_version() == 7) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
-  if (gemm_version() != 3) {
-    // Small problems (a rank's shard of a category on 8 GPUs): when the 256x256 tiles would fill at most
-    // half the CUs, the 256x128 kernel does the same work in one round of half-size tiles
-    // (measured at 11 images: ViT block 0.71 -> 0.61 ms with the smaller tile, equal from 21 images up).
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-        n_cu = 256;
-    }
-    const long long tiles5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-    if (gemm_version() == 8 && 2 * tiles5 > n_cu) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
-    if (gemm_version() != 8) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
-  }
-  // start stagger of the first tile round, in units of 64 cycles per CU slot (see gemm_hl2.h)
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("AC_STAGGER"); stagger = e ? atoi(e) : 0; }
-  return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream, 8, 0, 1, stagger);
+  const int policy = ac_gemm_policy();
+#ifdef AC_EXPERIMENTAL
+  if (policy == 101) return gemm::launch(A, B, M, N, K, epi, stream);
+  if (policy == 103) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
+  if (policy == 104) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
+  if (policy == 105) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
+#endif
+  const long long tiles5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && 2 * tiles5 > ac_device_cus());
+  if (big) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
+  return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream, 8, 0, 1);
 }
 
 __host__ __device__ inline int tpad_of(int T) { return (T + 31) / 32 * 32; }

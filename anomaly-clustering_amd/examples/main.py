@@ -11,7 +11,7 @@ matrix_alpha_X_{category}_{mode}.pickle``, plus ``{output_dir}/{dataset}/info/in
 Conscious differences:
   * --supervised selects the mode (reference overrides it with a hard-coded loop over both,
     main.py:348); ``--supervised both`` reproduces the reference's behaviour.
-  * ``--dataset synthetic`` (or a missing --path) uses MVTec-AD-shaped synthetic images.
+  * ``--dataset synthetic`` uses MVTec-AD-shaped synthetic images (only then: a mistyped --path fails).
   * images are embedded in batches and stay on the device; the normal-image bank of the
     supervised mode is a seeded permutation (reference: unseeded shuffle, main.py:274).
   * launched under torchrun, the images of each category are sharded over the ranks (RCCL).
@@ -55,7 +55,7 @@ def artefact_dir(save_path, layers_to_extract_from, pretrain_embed_dimension, ta
 
 
 def _dataset(path, category, split, dataset):
-    if dataset != "synthetic" and os.path.isdir(os.path.join(path, category)):
+    if dataset != "synthetic":          # a missing --path raises (mvtec.py), as the reference would
         return mvtec.MVTecDataset(source=path, split=split, classname=category, resize=256, imagesize=224)
     return synthetic.SyntheticMVTecDataset(source=path, split=synthetic.DatasetSplit(split.value),
                                            classname=category, resize=256, imagesize=224)
@@ -174,6 +174,8 @@ def main(argv=None):
     for supervised in modes:
         save_path = args.output_dir + "/" + args.dataset + "/" + args.backbone_names[0] + "/" + supervised
         os.makedirs(save_path, exist_ok=True)
+        with open(os.path.join(save_path, "WEIGHTS_SOURCE.txt"), "w") as f:     # random-init runs stay recognisable
+            f.write(str(getattr(backbone, "weights_source", "unknown")) + "\n")
         for category in (args.categories or _CLASSNAMES):
             results[(supervised, category)] = make_category_data(
                 path=args.path, category=category, pretrain_embed_dimension=args.pretrain_embed_dimension,

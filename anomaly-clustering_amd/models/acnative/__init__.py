@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AC_LIB") or os.path.join(_HERE, "libac_hip.so")   # AC_LIB: diagnostic builds only
 
+GEMM_AUTO, GEMM_256x128, GEMM_256x256 = 0, 1, 2
 REDUCE_MEAN_OTHERS = 0
 REDUCE_MIN_ALL = 1
 FEAT_TOKENS = 0
@@ -33,6 +34,7 @@ class BlockWeights(_c.Structure):
 SIGNATURES = {
     "ac_version": (_i, []),
     "ac_last_error": (_c.c_char_p, []),
+    "ac_set_gemm_policy": (_i, [_i]),
     "ac_pack_hl32": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "ac_vit_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ac_vit_prepare_tokens": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -79,6 +81,11 @@ def _check(rc):
         raise RuntimeError("libac_hip error %d: %s" % (rc, lib().ac_last_error().decode()))
 
 
+def set_gemm_policy(policy):
+    """Pin one of the two bit-identical linear-layer GEMM kernels (diagnostic; GEMM_AUTO = by size)."""
+    _check(lib().ac_set_gemm_policy(int(policy)))
+
+
 def _dev(t, dtype=None, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError("%s must be a tensor on the HIP device (got %s); the MI355X path has no CPU fallback"
@@ -98,12 +105,17 @@ _workspaces = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per device (uint8)."""
-    key = str(device)
+    """Grow-only scratch buffer (uint8) per (device, stream): every entry point launches on the current stream,
+    so calls on different streams never share scratch, and a buffer is only ever replaced by an allocation made
+    on its own stream (the caching allocator then orders the reuse of the old block after the queued kernels).
+    release_workspaces() gives the memory back (e.g. ~1 GB of packed operands after a large alpha call)."""
+    device = torch.device(device)
+    stream = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        _workspaces[key] = None
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
 

@@ -24,15 +24,24 @@ def _sources():
 
 def _deps_mtime():
     m = 0.0
-    for root in (CSRC, INCLUDE):
+    for root in (CSRC, os.path.join(CSRC, "experimental"), INCLUDE):
         for f in os.listdir(root):
             if f.endswith((".h", ".hip")):
                 m = max(m, os.path.getmtime(os.path.join(root, f)))
     return m
 
 
-def build(force=False, verbose=True):
-    """Compile if the library is missing or older than any source/header.  Returns the path."""
+def build(force=False, verbose=True, experimental=False):
+    """Compile if the library is missing or older than any source/header.  Returns the path.
+    experimental=True builds libac_hip_experimental.so with -DAC_EXPERIMENTAL instead: the superseded GEMM
+    generations under csrc/experimental/ become selectable through ac_set_gemm_policy(101..109) for same-box
+    A/B runs (load it with AC_LIB=...).  The product library never contains them."""
+    if experimental:
+        return _build(force, verbose, LIB[:-3] + "_experimental.so", OBJ_DIR + "_experimental", ["-DAC_EXPERIMENTAL"])
+    return _build(force, verbose, LIB, OBJ_DIR, [])
+
+
+def _build(force, verbose, LIB, OBJ_DIR, extra):
     srcs = _sources()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
         return LIB
@@ -43,7 +52,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -63,4 +72,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, experimental="--experimental" in sys.argv)

@@ -1,16 +1,22 @@
 """Backbone registry (reference: models/patchcore/backbones.py:53-79).
 
-On the hot path only the DINO names exist.  As in the reference, every DINO name builds
-``vit_base`` with the name's patch size (backbones.py:70).  The reference downloads the
-checkpoint from dl.fbaipublicfiles.com; here weights come from, in this order:
+On the ViT hot path the DINO names exist; as in the reference, every DINO name builds ``vit_base`` with the
+name's patch size (backbones.py:70).  The reference downloads the checkpoint from dl.fbaipublicfiles.com;
+here (no network) the weights come from
 
-  1. ``$AC_DINO_WEIGHTS/<checkpoint file name>`` or the file ``$AC_DINO_WEIGHTS`` itself
-     (a DINO-format ``state_dict`` saved with torch.save), loaded with ``strict=True``;
-  2. otherwise the seeded reference initialisation (``$AC_BACKBONE_SEED``, default 0) -
-     the benchmark/parity configuration (no network on the build or GPU boxes).
+  1. ``$AC_DINO_WEIGHTS/<checkpoint file name>`` or the file ``$AC_DINO_WEIGHTS`` itself (a DINO-format
+     ``state_dict`` saved with torch.save), loaded with ``strict=True``.  If the variable is set and the
+     file is not there, load() RAISES - it never silently substitutes other weights;
+  2. or, only when the caller opts in with ``$AC_BACKBONE_SEED=<int>``, the seeded reference initialisation
+     (trunc-normal 0.02 etc.: the benchmark / parity configuration).  The model then carries
+     ``weights_source = "random-init(seed=N)"``, a warning is printed, and examples/main.py writes that
+     string next to its artefacts.
+  With neither, load() raises: clustering with random weights must never look like a real run.
 
-The torchvision/timm names of the reference's table need those packages and a download;
-asking for one raises with that explanation.
+``wideresnet50`` (BASELINE config 1, reference backbones.py:27) needs torchvision for the real network; when
+torchvision is absent and ``$AC_BACKBONE_SEED`` is set, a seeded WRN50-SHAPED stand-in is returned
+(patchcore/standin_cnn.py: layer2 [512,28,28], layer3 [1024,14,14]) - torch convolutions, plumbing for the
+CPU/CLI path of config 1, NOT part of the MI355X hot path.  The other torchvision/timm names raise.
 """
 import os
 
@@ -36,15 +42,39 @@ def _find_weights(filename):
     return cand if os.path.isfile(cand) else None
 
 
+def _seed_opt_in(name):
+    seed = os.environ.get("AC_BACKBONE_SEED")
+    if seed is None:
+        raise RuntimeError(
+            "no weights for backbone %r: set AC_DINO_WEIGHTS to a DINO checkpoint (file or directory), or opt in "
+            "to the seeded random initialisation with AC_BACKBONE_SEED=<int> (benchmarks / parity tests only)" % name)
+    return int(seed)
+
+
 def load(name):
+    if name == "wideresnet50":
+        from patchcore import standin_cnn
+        seed = _seed_opt_in(name)
+        print("WARNING: backbone %r is a seeded WRN50-SHAPED stand-in (seed %d), not torchvision's pretrained "
+              "wide_resnet50_2: plumbing only" % (name, seed))
+        model = standin_cnn.wrn50_shaped(seed)
+        model.weights_source = "standin-random-init(seed=%d)" % seed
+        return model
     if name not in _DINO:
         raise NotImplementedError(
-            "backbone %r is outside the MI355X hot path (only %s); torchvision/timm backbones "
-            "need those packages and a weight download" % (name, sorted(_DINO)))
+            "backbone %r is outside the MI355X hot path (only %s + the wideresnet50 stand-in); torchvision/timm "
+            "backbones need those packages and a weight download" % (name, sorted(_DINO)))
     filename, patch_size = _DINO[name]
     path = _find_weights(filename)
+    if path is None and os.environ.get("AC_DINO_WEIGHTS"):
+        raise FileNotFoundError("AC_DINO_WEIGHTS=%r is set but %r was not found there"
+                                % (os.environ["AC_DINO_WEIGHTS"], filename))
+    source = path
     if path is None:
-        torch.manual_seed(int(os.environ.get("AC_BACKBONE_SEED", "0")))
+        seed = _seed_opt_in(name)
+        torch.manual_seed(seed)
+        source = "random-init(seed=%d)" % seed
+        print("WARNING: backbone %r runs on SEEDED RANDOM weights (%s), not the DINO checkpoint" % (name, source))
     model = vits.vit_base(patch_size=patch_size, num_classes=0)
     for p in model.parameters():
         p.requires_grad = False
@@ -52,6 +82,7 @@ def load(name):
     if path is not None:
         state = torch.load(path, map_location="cpu", weights_only=True)
         model.load_state_dict(state, strict=True)
+    model.weights_source = source
     if torch.cuda.is_available():
         model.to(torch.device("cuda"))
     return model

@@ -124,6 +124,7 @@ def main():
     from patchcore.pipeline import HipOps, run_category
     from patchcore.datasets import synthetic
 
+    os.environ.setdefault("AC_BACKBONE_SEED", "0")       # random-init weights of the named architecture (no checkpoint offline)
     backbone = patchcore.backbones.load("dino_vitbase8")
     core = AnomalyClusteringCore(dev)
     core.load(backbone=backbone, layers_to_extract_from=["blocks.10", "blocks.11"], device=dev,

@@ -24,8 +24,13 @@
  *     high halves (fp16(x)) followed by the 32 low halves (fp16(x - hi)) of the
  *     same 32 columns.  hi+lo carries 22 significand bits, and the 3-pass
  *     product hi*hi + hi*lo + lo*hi accumulated in fp32 by
- *     v_mfma_f32_32x32x16_f16 is at least as accurate as an fp32 FMA chain
+ *     v_mfma_f32_16x16x32_f16 is at least as accurate as an fp32 FMA chain
  *     (measured: profiles/r01_mfma_probe.txt).
+ *   - devices: every call runs on the device that is current on the calling thread
+ *     (hipSetDevice) and on the stream it is given; what the library caches (CU
+ *     count, kernel attributes) is keyed by that device, so a process may drive
+ *     several GPUs.  The ONE piece of process-wide state is the diagnostic GEMM
+ *     policy (ac_set_gemm_policy), which never changes results.
  */
 #ifndef AC_HIP_H
 #define AC_HIP_H
@@ -44,6 +49,14 @@ extern "C" {
 
 int ac_version(void);
 const char* ac_last_error(void);
+
+/* Diagnostic knob, process-wide: which of the two (bit-identical) linear-layer GEMM kernels the ViT
+ * entry points launch.  AUTO picks by problem size.  Exists so that tests can prove the two agree
+ * and so that same-box A/B timings need no rebuild. */
+#define AC_GEMM_AUTO 0
+#define AC_GEMM_256x128 1 /* csrc/gemm_hl2.h */
+#define AC_GEMM_256x256 2 /* csrc/gemm_hl5.h */
+int ac_set_gemm_policy(int policy);
 
 /* ------------------------------------------------------------------ operands */
 

@@ -13,6 +13,10 @@ for p in (ROOT, MODELS, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# the tests run the seeded reference initialisation (no checkpoint offline): explicit opt-in, see backbones.py
+os.environ.setdefault("AC_BACKBONE_SEED", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

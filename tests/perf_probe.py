@@ -25,6 +25,8 @@ def main():
     import acnative
     what = sys.argv[1]
     dev = torch.device("cuda:0")
+    if os.environ.get("AC_POLICY"):                  # experimental builds (AC_LIB=...): pin a GEMM generation
+        acnative.set_gemm_policy(int(os.environ["AC_POLICY"]))
     if what == "alpha":
         N = int(sys.argv[2])
         g = torch.Generator(device="cpu").manual_seed(0)

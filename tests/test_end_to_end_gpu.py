@@ -77,11 +77,11 @@ def test_main_then_test_scripts_match_oracle(tmp_path, dev, small_model, mode, m
 
     out = str(tmp_path / "outputs")
     layers = ["blocks.2", "blocks.3"]
-    save_path = out + "/mvtec_ad/dino_vitbase8/" + mode
+    save_path = out + "/synthetic/dino_vitbase8/" + mode
     alpha, X = main.make_category_data(
         path="nowhere", category="grid", pretrain_embed_dimension=2048, target_embed_dimension=4096,
         backbone_names=["dino_vitbase8"], layers_to_extract_from=layers, patchsize=3, save_path=save_path,
-        tau=1, train_ratio=1.0, supervised=mode, dataset="mvtec_ad", info_dir=out + "/mvtec_ad/info",
+        tau=1, train_ratio=1.0, supervised=mode, dataset="synthetic", info_dir=out + "/synthetic/info",
         backbone=small_model, batch_size=8)
     n = X.shape[0]
     assert alpha.shape == (n, 1, 784) and alpha.dtype == torch.float32 and X.dtype == np.float32 and X.shape == (n, 4096)
@@ -101,7 +101,7 @@ def test_main_then_test_scripts_match_oracle(tmp_path, dev, small_model, mode, m
     NMI, ARI, F1, label, predict = test_mod.calculate_metrics(
         category="grid", pretrain_embed_dimension=2048, target_embed_dimension=4096,
         backbone_names=["dino_vitbase8"], layers_to_extract_from=layers, patchsize=3, train_ratio=1.0, tau=1,
-        supervised=mode, dataset="mvtec_ad", output_dir=out)
+        supervised=mode, dataset="synthetic", output_dir=out)
     rN, rA, rF, rl, rp = ocluster.calculate_metrics(X_ref, list(test_ds.anomalies))
     print(mode, "NMI/ARI/F1 ours %.4f %.4f %.4f  oracle %.4f %.4f %.4f" % (NMI, ARI, F1, rN, rA, rF))
     assert abs(NMI - rN) <= 1e-3 and abs(ARI - rA) <= 1e-3 and abs(F1 - rF) <= 1e-3

@@ -1,6 +1,9 @@
 """Where the 256x256 GEMM's k loop waits (diagnostic; needs a -DAC_TILE_TIMING build, see tile_timing.py).
 
-    AC_LIB=$PWD/build_ablate/libac_timing.so AC_GEMM=8 python tests/wait_timing.py 48
+    AC_LIB=$PWD/build_ablate/libac_timing.so python tests/wait_timing.py 48
+
+(the timing library is built with -DAC_EXPERIMENTAL -DAC_TILE_TIMING: policy 108 routes the all-pairs problem
+through the 256x256 kernel, which the product uses for the ViT layers only)
 
 Runs the general all-pairs problem once and prints, per workgroup (medians), the shader-clock cycles of
 the k loop and the share wave 0 spent waiting at the X barrier (DMA landed) and the Y barrier (fragment
@@ -23,6 +26,7 @@ def main():
     torch.manual_seed(0)
     Z = torch.randn(n, 784, 4096, device=dev)
     Zc = Z.clone()
+    acnative.set_gemm_policy(108)
     acnative.pair_min_dist_staged(Z, Zc, 0)
     acnative.pair_min_dist_staged(Z, Zc, 0)
     torch.cuda.synchronize()
