@@ -60,12 +60,15 @@ extern "C" int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_l
 // atomicMin per (key image, query column) into minbuf[key_image][query] (d2 >= 0, so the
 // IEEE bit pattern orders like an unsigned integer).
 struct EpiPairMin {
-  const float* key_sq;   // [M]
-  const float* qry_sq;   // [N]
-  unsigned* minbuf;      // [n_key_images][N]
+  const float* key_sq;   // [M]  squared norms of the A rows
+  const float* qry_sq;   // [N]  squared norms of the B rows
+  unsigned* minbuf;      // [images of A][N]: min over the A patches of one image, per B patch
+  unsigned* minbuf_t;    // [images of B][M]: the other direction (symmetric: == minbuf; two-way: its own matrix)
   int M, N, P;
+  // upper_only (diagonal blocks of a symmetric problem): elements with row > column are left out - the
+  // mirror element, formed with the lower row as the A operand, stands for both.
   template <class F>
-  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane) const {
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane, bool upper_only = false) const {
     if (m_wave >= M) return;                      // wave-uniform
     const int m_end = min(m_wave + 64, M);
     float ksq[F::NT][F::NR];
@@ -82,8 +85,10 @@ struct EpiPairMin {
 #pragma unroll
       for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < F::NR; ++i)   // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
-          d2[mi][i] = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+        for (int i = 0; i < F::NR; ++i) {  // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
+          const float v = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+          d2[mi][i] = (upper_only && m_wave + F::row(mi, i, lane) > col) ? __builtin_inff() : v;
+        }
       for (int img = img_first; img <= img_last; ++img) {   // wave-uniform trip count (<= 2 when P >= 64)
         const int lo = img * P, hi = min(lo + P, m_end);
         float mn = __builtin_inff();
@@ -100,12 +105,12 @@ struct EpiPairMin {
     }
   }
 
-  // Symmetric case (keys == queries, M == N): the same tile read the other way - the block's ROWS
-  // are the query patches, its COLUMNS the key patches.  One TW-column slab of the wave's d2 at a time
+  // The same tile read the other way - the block's ROWS are the query patches, its COLUMNS the key
+  // patches (symmetric case: keys == queries, M == N; two-way case: a rectangle between two row sets).  One TW-column slab of the wave's d2 at a time
   // goes through LDS transposed ([column][row], 65-float pitch), then lane l owns row l and takes the
   // min over the columns of each key image.
   template <class F>
-  __device__ void transposed(const F& f, int m_wave, int n_wave, int lane, float* tb) const {
+  __device__ void transposed(const F& f, int m_wave, int n_wave, int lane, float* tb, bool upper_only = false) const {
     if (m_wave >= M || n_wave >= N) return;       // wave-uniform
     float ksq[F::NT][F::NR];
 #pragma unroll
@@ -122,8 +127,11 @@ struct EpiPairMin {
 #pragma unroll
       for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < F::NR; ++i)
-          tb[cl * 65 + F::row(mi, i, lane)] = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+        for (int i = 0; i < F::NR; ++i) {
+          const float v = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+          tb[cl * 65 + F::row(mi, i, lane)] =
+              (upper_only && m_wave + F::row(mi, i, lane) > c_base + cl) ? __builtin_inff() : v;
+        }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       const int c_end = min(c_base + F::TW, N);
@@ -131,13 +139,14 @@ struct EpiPairMin {
         const int lo = max(img * P, c_base) - c_base, hi = min((img + 1) * P, c_end) - c_base;
         float mn = __builtin_inff();
         for (int c = lo; c < hi; ++c) mn = fminf(mn, tb[c * 65 + lane]);
-        if (my_row < M) atomicMin(minbuf + (size_t)img * N + my_row, __float_as_uint(mn));
+        if (my_row < M) atomicMin(minbuf_t + (size_t)img * M + my_row, __float_as_uint(mn));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
   }
-  bool symmetric;
+  bool symmetric;        // A == B: only the upper triangle of tiles runs, each reduced both ways into minbuf
+  bool two_way;          // A != B, both directions wanted: every tile of the rectangle is reduced both ways
 };
 template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; static constexpr bool kStaged = false; };
 
@@ -151,7 +160,7 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
                            int part = 0, int nparts = 1) {
   const int group_m = epi.symmetric ? 4 : 8;
 #ifdef AC_EXPERIMENTAL
-  const int v = ac_gemm_policy();
+  const int v = epi.two_way ? 0 : ac_gemm_policy();
   if (v == 101 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
   if (v == 103 && nparts == 1 && !epi.symmetric) return gemm3::launch(A, B, M, N, K, epi, stream, 4);
   if (v == 104) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
@@ -169,23 +178,97 @@ __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
   for (; i < n; i += stride) p[i] = v;
 }
 
-// w[q_img][p] from minbuf[key_img][q]: sqrt, then mean over key images != self, or min over all.
-__global__ void reduce_pairs_kernel(const unsigned* __restrict__ minbuf, int64_t nk, int64_t ncols, int P,
-                                    int reduce, int64_t self_first, float* __restrict__ w) {
+// ---------------------------------------------------- from min d2 to the weights w
+// minbuf[j][col] (min d2 between query patch `col` and key image j) -> w.  The unsupervised mean runs
+// over ALL key images of the category, which a large or sharded problem sees block by block, on different
+// ranks, in any order - so the sum is kept in 64-bit FIXED POINT: each sqrt (an fp32 value) is scaled by
+// 2^shift and rounded to an integer, and integer addition is associative.  Any blocking, any rank count and
+// atomics all give the same bits; one rounding to fp32 at the end.  shift comes from the data: the largest
+// power of two (capped at 40, i.e. a resolution of 9e-13) for which n_keys * 2 sqrt(max |z|^2) stays
+// below 2^62.  The supervised min needs none of this: min over uint32 bit patterns is exact.
+__global__ void max_f32_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+extern "C" int ac_max_f32(const float* x, int64_t n, float* out, void* stream) {
+  AC_REQUIRE(out && (x || n <= 0), "ac_max_f32: null pointer");
+  if (n <= 0) return AC_OK;
+  unsigned grid = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+  hipLaunchKernelGGL(max_f32_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, n, reinterpret_cast<unsigned*>(out));
+  return ac_check_launch("ac_max_f32");
+}
+
+__global__ void fixed_shift_kernel(const float* __restrict__ max_sq, int64_t n_keys, int* __restrict__ shift) {
+  // every distance is <= |a| + |b| <= 2 sqrt(max_sq); bound = n_keys of them (+1: never log2(0))
+  const double bound = (double)(n_keys > 0 ? n_keys : 1) * 2.0 * sqrt((double)max_sq[0]) + 1.0;
+  int e = 0;
+  (void)frexp(bound, &e);                       // bound < 2^e
+  int s = 62 - e;
+  shift[0] = s > 40 ? 40 : (s < -60 ? -60 : s);
+}
+
+extern "C" int ac_pair_fixed_shift(const float* max_sq, int64_t n_keys, int32_t* shift, void* stream) {
+  AC_REQUIRE(max_sq && shift, "ac_pair_fixed_shift: null pointer");
+  hipLaunchKernelGGL(fixed_shift_kernel, dim3(1), dim3(1), 0, as_stream(stream), max_sq, n_keys, shift);
+  return ac_check_launch("ac_pair_fixed_shift");
+}
+
+__global__ void pair_accumulate_kernel(const unsigned* __restrict__ minbuf, int64_t nk, int64_t ld, int64_t ncols, int P,
+                                       int reduce, int64_t self_first, const int* __restrict__ shift_p,
+                                       void* __restrict__ acc) {
   int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncols) return;
-  int64_t self = self_first + col / P;
   if (reduce == AC_REDUCE_MEAN_OTHERS) {
-    double s = 0.0;
+    const int64_t self = self_first + col / P;
+    const double scale = ldexp(1.0, shift_p[0]);
+    long long s = 0;
     for (int64_t j = 0; j < nk; ++j)
-      if (j != self) s += (double)sqrtf(__uint_as_float(minbuf[j * ncols + col]));
-    int64_t cnt = nk - ((self >= 0 && self < nk) ? 1 : 0);
-    w[col] = (float)(s / (double)cnt);          // cnt == 0 -> NaN, as torch.mean of an empty tensor
+      if (j != self) s += __double2ll_rn((double)sqrtf(__uint_as_float(minbuf[j * ld + col])) * scale);
+    static_cast<long long*>(acc)[col] += s;      // one thread per column, launches on one stream are ordered
   } else {
-    float m = __builtin_inff();
-    for (int64_t j = 0; j < nk; ++j) m = fminf(m, __uint_as_float(minbuf[j * ncols + col]));
-    w[col] = sqrtf(m);
+    unsigned m = static_cast<unsigned*>(acc)[col];
+    for (int64_t j = 0; j < nk; ++j) m = min(m, minbuf[j * ld + col]);
+    static_cast<unsigned*>(acc)[col] = m;
   }
+}
+
+extern "C" int ac_pair_accumulate(const uint32_t* minbuf, int64_t nk, int64_t ld, int64_t ncols, int P, int reduce,
+                                  int64_t self_first, const int32_t* shift, void* acc, void* stream) {
+  AC_REQUIRE(minbuf && acc, "ac_pair_accumulate: null pointer");
+  AC_REQUIRE(nk >= 0 && ncols >= 0 && ld >= ncols && P > 0, "ac_pair_accumulate: bad shape");
+  AC_REQUIRE(reduce == AC_REDUCE_MEAN_OTHERS || reduce == AC_REDUCE_MIN_ALL, "ac_pair_accumulate: bad reduce=%d", reduce);
+  AC_REQUIRE(reduce == AC_REDUCE_MIN_ALL || shift, "ac_pair_accumulate: the mean needs the fixed-point shift");
+  if (nk == 0 || ncols == 0) return AC_OK;
+  hipLaunchKernelGGL(pair_accumulate_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, as_stream(stream), minbuf,
+                     nk, ld, ncols, P, reduce, self_first, shift, acc);
+  return ac_check_launch("ac_pair_accumulate");
+}
+
+__global__ void pair_finalize_kernel(const void* __restrict__ acc, int64_t ncols, int reduce, int64_t count,
+                                     const int* __restrict__ shift_p, float* __restrict__ w) {
+  int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  if (reduce == AC_REDUCE_MEAN_OTHERS) {
+    const double sum = ldexp((double)static_cast<const long long*>(acc)[col], -shift_p[0]);
+    w[col] = (float)(sum / (double)count);        // count == 0 -> NaN, as torch.mean of an empty tensor
+  } else {
+    w[col] = sqrtf(__uint_as_float(static_cast<const unsigned*>(acc)[col]));
+  }
+}
+
+extern "C" int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift, float* w,
+                                void* stream) {
+  AC_REQUIRE(acc && w, "ac_pair_finalize: null pointer");
+  AC_REQUIRE(reduce == AC_REDUCE_MEAN_OTHERS || reduce == AC_REDUCE_MIN_ALL, "ac_pair_finalize: bad reduce=%d", reduce);
+  AC_REQUIRE(reduce == AC_REDUCE_MIN_ALL || shift, "ac_pair_finalize: the mean needs the fixed-point shift");
+  if (ncols <= 0) return AC_OK;
+  hipLaunchKernelGGL(pair_finalize_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, as_stream(stream), acc,
+                     ncols, reduce, count, shift, w);
+  return ac_check_launch("ac_pair_finalize");
 }
 
 static const size_t kMinbufBudget = (size_t)1 << 30;   // bytes of minbuf per query chunk
@@ -202,7 +285,8 @@ extern "C" size_t ac_pair_min_dist_workspace_bytes(int64_t nq, int64_t nk, int P
   size_t hl_k = align_up((size_t)nk * P * D * 4, 256), hl_q = align_up((size_t)nq * P * D * 4, 256);
   size_t n_k = align_up((size_t)nk * P * 4, 256), n_q = align_up((size_t)nq * P * 4, 256);
   size_t mb = align_up((size_t)query_chunk(nq, nk, P) * P * nk * 4, 256);
-  return hl_k + hl_q + n_k + n_q + mb + 1024;
+  size_t acc = align_up((size_t)nq * P * 8, 256);
+  return hl_k + hl_q + n_k + n_q + mb + acc + 512 + 1024;
 }
 
 extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, int P, int D, int reduce,
@@ -225,6 +309,9 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
   float* sq = same ? sk : ar.take<float>((size_t)nq * P);
   const int64_t chunk = query_chunk(nq, nk, P);
   unsigned* minbuf = ar.take<unsigned>((size_t)chunk * P * nk);
+  long long* acc = ar.take<long long>((size_t)nq * P);
+  float* max_sq = ar.take<float>(64);
+  int32_t* shift = reinterpret_cast<int32_t*>(max_sq + 32);
   if (!ar.ok()) return ac_fail(AC_EWORKSPACE, "ac_pair_min_dist: workspace carve failed");
 
   int rc = ac_pack_hl32(Zk, nk * P, D, D, hk, sk, stream_);
@@ -233,6 +320,18 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
     rc = ac_pack_hl32(Zq, nq * P, D, D, hq, sq, stream_);
     if (rc) return rc;
   }
+  const bool mean = reduce == AC_REDUCE_MEAN_OTHERS;
+  const size_t ncols_all = (size_t)nq * P;
+  if (mean) {
+    if (hipMemsetAsync(max_sq, 0, 256, stream) != hipSuccess || hipMemsetAsync(acc, 0, ncols_all * 8, stream) != hipSuccess)
+      return ac_fail(AC_ELAUNCH, "ac_pair_min_dist: hipMemsetAsync failed");
+    if ((rc = ac_max_f32(sk, nk * P, max_sq, stream_))) return rc;
+    if (!same && (rc = ac_max_f32(sq, nq * P, max_sq, stream_))) return rc;
+    if ((rc = ac_pair_fixed_shift(max_sq, nk, shift, stream_))) return rc;
+  } else {
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((ncols_all + 255) / 256 < 4096 ? (ncols_all + 255) / 256 : 4096)),
+                       dim3(256), 0, stream, reinterpret_cast<unsigned*>(acc), ncols_all, 0x7f800000u);
+  }
   const int M = (int)(nk * P);
   for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
     const int64_t qn = (q0 + chunk <= nq) ? chunk : nq - q0;
@@ -240,37 +339,39 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
     size_t cells = (size_t)nk * N;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096)),
                        dim3(256), 0, stream, minbuf, cells, 0x7f800000u);
-    EpiPairMin epi{sk, sq + q0 * P, minbuf, M, N, P, same && chunk == nq};   // whole square in one launch -> C = C^T
+    // whole square in one launch -> C = C^T
+    EpiPairMin epi{sk, sq + q0 * P, minbuf, minbuf, M, N, P, same && chunk == nq, false};
     rc = launch_pair_min(hk, hq + (size_t)q0 * P * D * 4, M, N, D, epi, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, minbuf, nk,
-                       (int64_t)N, P, reduce, self_offset + q0, w + q0 * P);
+    void* acc_q = mean ? static_cast<void*>(acc + q0 * P) : static_cast<void*>(reinterpret_cast<unsigned*>(acc) + q0 * P);
+    if ((rc = ac_pair_accumulate(minbuf, nk, N, N, P, reduce, self_offset + q0, shift, acc_q, stream_))) return rc;
   }
-  return ac_check_launch("ac_pair_min_dist");
+  int64_t count = nk;
+  if (mean) {
+    // every query image must see the same number of "other" key images: self_offset places the queries inside
+    // the key list (or outside it: then nothing is skipped)
+    const bool inside = self_offset >= 0 && self_offset + nq <= nk;
+    const bool outside = self_offset + nq <= 0 || self_offset >= nk;
+    AC_REQUIRE(inside || outside, "ac_pair_min_dist: the query block must lie wholly inside or outside the key list");
+    count = inside ? nk - 1 : nk;
+  }
+  return ac_pair_finalize(acc, (int64_t)ncols_all, reduce, count, shift, w, stream_);
 }
 
-// Staged form of the same computation (pack -> min-d2 GEMM -> reduce) for callers that keep the
-// packed operands resident across calls or want to time the MFMA kernel on its own.
+// Staged form of the same computation (pack -> min-d2 GEMM -> accumulate -> finalize) for callers that keep
+// the packed operands resident, shard the category over GPUs, or time the MFMA kernel on its own.
 extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64_t nk, const void* Zq_hl,
-                                     const float* q_sq, int64_t nq, int P, int D, uint32_t* minbuf, int part,
-                                     int nparts, void* stream) {
+                                     const float* q_sq, int64_t nq, int P, int D, uint32_t* minbuf, uint32_t* minbuf_t,
+                                     int part, int nparts, void* stream) {
   AC_REQUIRE(Zk_hl && k_sq && Zq_hl && q_sq && minbuf, "ac_pair_min_sq_packed: null pointer");
   AC_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "ac_pair_min_sq_packed: bad part %d/%d", part, nparts);
   AC_REQUIRE(nq > 0 && nk > 0 && P > 0 && D > 0 && D % 32 == 0, "ac_pair_min_sq_packed: bad shape");
   AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_sq_packed: too many patches");
-  EpiPairMin epi{k_sq, q_sq, minbuf, (int)(nk * P), (int)(nq * P), P, Zk_hl == Zq_hl && nk == nq};
+  const bool same = Zk_hl == Zq_hl && nk == nq;
+  AC_REQUIRE(!(same && minbuf_t), "ac_pair_min_sq_packed: keys == queries is the symmetric case; minbuf_t must be NULL");
+  AC_REQUIRE(!(minbuf_t && nparts != 1), "ac_pair_min_sq_packed: two-way blocks are not sliced");
+  EpiPairMin epi{k_sq, q_sq, minbuf, same ? minbuf : minbuf_t, (int)(nk * P), (int)(nq * P), P, same, minbuf_t != nullptr};
   return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), part, nparts);
-}
-
-extern "C" int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,
-                              float* w, void* stream) {
-  AC_REQUIRE(minbuf && w, "ac_pair_reduce: null pointer");
-  AC_REQUIRE(nq > 0 && nk > 0 && P > 0, "ac_pair_reduce: bad shape");
-  AC_REQUIRE(reduce == AC_REDUCE_MEAN_OTHERS || reduce == AC_REDUCE_MIN_ALL, "ac_pair_reduce: bad reduce=%d", reduce);
-  int64_t N = nq * P;
-  hipLaunchKernelGGL(reduce_pairs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), minbuf, nk,
-                     N, P, reduce, self_first, w);
-  return ac_check_launch("ac_pair_reduce");
 }
 
 // ------------------------------------------------------------ alpha softmax

@@ -288,10 +288,21 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
         // rb == cb one way, rb > cb (lower part of a diagonal tile) is its mirror image's job.
         // NT == 8: 64-blocks of a square tile; NT == 4: 128-blocks of a 256x128 tile (gemm_hl2.h).
         const int rb = NT == 8 ? tm * 4 + wm : 2 * tm + (wm >> 1), cb = NT == 8 ? tn * 4 + wn * 2 + no : tn;
-        if (rb <= cb) epi(f, m_wave, n_wave, lane);
-        if (rb < cb) epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65));
+        // Every product a.b is formed with the LOWER patch row as the A operand and reduced in both
+        // directions - also inside the diagonal blocks, where only the elements on or above the diagonal are
+        // used.  The three split-fp16 passes are accumulated in a fixed order, so a.b and b.a differ in the
+        // last bit; with one orientation per unordered pair the result does not depend on where tile and block
+        // boundaries fall, which is what makes blocked / sharded runs bit-identical to a single launch.
+        const bool diag = rb == cb;
+        if (rb < cb || (diag && m_wave <= n_wave + 63)) {
+          epi(f, m_wave, n_wave, lane, diag);
+          epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65), diag);
+        }
       } else {
         epi(f, m_wave, n_wave, lane);
+        // two-way rectangle (A and B are different row sets of one symmetric problem): every tile is also
+        // reduced the other way, into the epilogue's second matrix
+        if (epi.two_way) epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65));
       }
     } else {
       epi(f, m_wave, n_wave, lane);

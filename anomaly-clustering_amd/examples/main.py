@@ -61,12 +61,6 @@ def _dataset(path, category, split, dataset):
                                            classname=category, resize=256, imagesize=224)
 
 
-def _stack_images(ds):
-    if hasattr(ds, "images"):            # synthetic dataset: already one tensor
-        return ds.images
-    return torch.stack([ds[i]["image"] for i in range(len(ds))])
-
-
 def make_category_data(path, category, pretrain_embed_dimension, target_embed_dimension, backbone_names,
                        layers_to_extract_from, patchsize, save_path, train_ratio=1.0, tau=1, supervised="unsupervised",
                        dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=32):
@@ -80,7 +74,6 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
     backbone_name = backbone_names[0]
 
     test_dataset = _dataset(path, category, mvtec.DatasetSplit.TEST, dataset)
-    test_dataloader = torch.utils.data.DataLoader(test_dataset, batch_size=1, shuffle=False, num_workers=0)
 
     if len(backbone_names) > 1:
         coll = [[] for _ in range(len(backbone_names))]
@@ -104,20 +97,13 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
               target_embed_dimension=target_embed_dimension, patchsize=patchsize, featuresampler=sampler,
               anomaly_scorer_num_nn=anomaly_scorer_num_nn, nn_method=nn_method)
 
-    # per-image records (collated with batch size 1, minus pixels) - what test.py reads as `info`
-    info = []
-    with tqdm(total=len(test_dataloader)) as progress:
-        for item in test_dataloader:
-            if isinstance(item, dict):
-                del item['image']
-                del item['mask']
-                info.append(item)
-            progress.update(1)
-
-    images = _stack_images(test_dataset)
+    # ONE pass over each split: decode on the host, resize / crop / normalise on the GPU, and collect the per-image
+    # records (what test.py reads as `info`: the item dicts minus pixels, collated with batch size 1) on the way.
+    # The reference walks the test set twice with batch size 1 (main.py:254-262, :266).
+    images, info = test_dataset.load_category(device)
     train_images = None
     if supervised == "supervised":
-        train_images = _stack_images(_dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset))
+        train_images, _ = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset).load_category(device)
     out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
                        train_images=train_images, train_ratio=train_ratio, want_pdist=False)
     # `tau` may be a list (a sweep): embeddings and patch distances were computed once; one artefact per tau

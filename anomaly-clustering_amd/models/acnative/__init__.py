@@ -36,6 +36,8 @@ SIGNATURES = {
     "ac_last_error": (_c.c_char_p, []),
     "ac_set_gemm_policy": (_i, [_i]),
     "ac_pack_hl32": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),
+    "ac_preprocess_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ac_preprocess_images": (_i, [_vp, _i, _i, _i, _i, _i, _c.POINTER(_f), _c.POINTER(_f), _vp, _vp, _sz, _vp]),
     "ac_vit_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ac_vit_prepare_tokens": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ac_vit_block": (_i, [_c.POINTER(BlockWeights), _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
@@ -47,8 +49,11 @@ SIGNATURES = {
     "ac_adaptive_avg_pool_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "ac_pair_min_dist_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
     "ac_pair_min_dist": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
-    "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _i, _i, _vp]),
-    "ac_pair_reduce": (_i, [_vp, _i64, _i64, _i, _i, _i64, _vp, _vp]),
+    "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ac_max_f32": (_i, [_vp, _i64, _vp, _vp]),
+    "ac_pair_fixed_shift": (_i, [_vp, _i64, _vp, _vp]),
+    "ac_pair_accumulate": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i64, _vp, _vp, _vp]),
+    "ac_pair_finalize": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
@@ -135,6 +140,28 @@ def pack_hl32(mat, want_sqnorm=False):
     return (out, sq) if want_sqnorm else out
 
 
+# ------------------------------------------------------------ input pipeline
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_images(images_u8, resize=256, crop=224, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 device tensor [B, H, W, 3] (decoded RGB) -> fp32 [B, 3, crop, crop]: Resize / CenterCrop /
+    ToTensor / Normalize of mvtec.py:74-81 in one batched call, bit-identical to the Pillow + torch host chain."""
+    p = _dev(images_u8, torch.uint8, "images")
+    if images_u8.dim() != 4 or images_u8.shape[3] != 3:
+        raise ValueError("images must be uint8 [B, H, W, 3], got %s" % (tuple(images_u8.shape),))
+    B, H, W, _ = images_u8.shape
+    out = torch.empty((B, 3, crop, crop), dtype=torch.float32, device=images_u8.device)
+    if B == 0:
+        return out
+    n = lib().ac_preprocess_workspace_bytes(B, H, W, resize, crop)
+    ws = workspace(n, images_u8.device)
+    m, s = (_f * 3)(*[float(v) for v in mean]), (_f * 3)(*[float(v) for v in std])
+    _check(lib().ac_preprocess_images(p, B, H, W, resize, crop, m, s, out.data_ptr(), ws.data_ptr(), n, _stream()))
+    return out
+
+
 # ----------------------------------------------------------------------- ViT
 def _f32(t):
     return t.detach().to(torch.float32).contiguous()
@@ -216,9 +243,9 @@ def layernorm_rows(x, norm):
 
 
 # --------------------------------------------------------- patch aggregation
-def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5):
+def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5, out=None):
     """features: list of fp32 device tensors, each [B, T, C] (token map with CLS) or [B, C, H, W].
-    Returns Z fp32 [B * H0 * W0, tgt_dim] and the per-layer patch grids."""
+    Returns Z fp32 [B * H0 * W0, tgt_dim] (written into `out` when given) and the per-layer patch grids."""
     n = len(features)
     feats = [f.to(torch.float32).contiguous() for f in features]
     ptrs = (_vp * n)(*[_dev(f, torch.float32, "feature") for f in feats])
@@ -238,7 +265,13 @@ def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5):
             raise ValueError("feature maps disagree on batch size")
     nbytes = lib().ac_patch_aggregate_workspace_bytes(n, Cs, Hs, Ws, B, patchsize, pre_dim, tgt_dim)
     ws = workspace(nbytes, feats[0].device)
-    Z = torch.empty((B * Hs[0] * Ws[0], tgt_dim), dtype=torch.float32, device=feats[0].device)
+    if out is None:
+        Z = torch.empty((B * Hs[0] * Ws[0], tgt_dim), dtype=torch.float32, device=feats[0].device)
+    else:
+        _dev(out, torch.float32, "out")
+        if out.numel() != B * Hs[0] * Ws[0] * tgt_dim or out.device != feats[0].device:
+            raise ValueError("out has %d elements, the batch needs %d" % (out.numel(), B * Hs[0] * Ws[0] * tgt_dim))
+        Z = out.view(B * Hs[0] * Ws[0], tgt_dim)
     _check(lib().ac_patch_aggregate(ptrs, kinds, Cs, Hs, Ws, n, B, patchsize, pre_dim, tgt_dim, float(eps),
                                     Z.data_ptr(), ws.data_ptr(), nbytes, _stream()))
     return Z, [[Hs[j], Ws[j]] for j in range(n)]
@@ -282,44 +315,147 @@ def pair_min_dist(Zq, Zk, reduce, self_offset=0):
     return w
 
 
-kernel_events = None   # set to a list to collect (label, start, stop) torch events around MFMA launches
+kernel_events = None   # set to a list to collect (label, start, stop, ...) torch events around MFMA launches
+NO_SELF = -(1 << 62)   # self_first value that skips nothing in pair_accumulate
+INF_BITS = 0x7f800000
+
+
+class Packed:
+    """hl32 image of a block of images: hl uint8 [n*P, D*4], sq fp32 [n*P] (squared row norms)."""
+
+    def __init__(self, hl, sq, n, P, D):
+        self.hl, self.sq, self.n, self.P, self.D = hl, sq, n, P, D
+
+    def slice(self, lo, hi):
+        """Images [lo, hi) as views (rows are image-major, so a block of images is a block of rows)."""
+        P = self.P
+        return Packed(self.hl[lo * P: hi * P], self.sq[lo * P: hi * P], hi - lo, P, self.D)
+
+    def tensors(self):
+        return [self.hl, self.sq]
+
+    @staticmethod
+    def empty(n, P, D, device):
+        return Packed(torch.empty((n * P, D * 4), dtype=torch.uint8, device=device),
+                      torch.empty((n * P,), dtype=torch.float32, device=device), n, P, D)
+
+
+def pack_images(Z):
+    """Z fp32 [n, P, D] -> Packed (one pass: split-fp16 image + squared norms)."""
+    _dev(Z, torch.float32, "Z")
+    n, P, D = Z.shape
+    if n == 0:
+        return Packed.empty(0, P, D, Z.device)
+    hl, sq = pack_hl32(Z.reshape(n * P, D), want_sqnorm=True)
+    return Packed(hl, sq, n, P, D)
+
+
+def max_sq(packed_list, device):
+    """Running max of the squared norms over several packed blocks: fp32 [1] on the device."""
+    out = torch.zeros(1, dtype=torch.float32, device=device)
+    for pk in packed_list:
+        if pk.n:
+            _check(lib().ac_max_f32(pk.sq.data_ptr(), pk.sq.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def fixed_shift(max_sq_t, n_keys):
+    """int32 [1] on the device: the fixed-point scale of the unsupervised sum over n_keys key images."""
+    shift = torch.empty(1, dtype=torch.int32, device=max_sq_t.device)
+    _check(lib().ac_pair_fixed_shift(_dev(max_sq_t, torch.float32, "max_sq"), int(n_keys), shift.data_ptr(), _stream()))
+    return shift
+
+
+def new_acc(ncols, reduce, device):
+    """Accumulator of pair_accumulate: int64 zeros (mean) or uint32-as-int32 +inf bits (min)."""
+    if reduce == REDUCE_MEAN_OTHERS:
+        return torch.zeros(ncols, dtype=torch.int64, device=device)
+    return torch.full((ncols,), INF_BITS, dtype=torch.int32, device=device)
+
+
+def _event_pair():
+    if kernel_events is None:
+        return None, None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    return ev0, ev1
+
+
+def pair_block(keys, queries, two_way=False, part=0, nparts=1):
+    """One MFMA launch on the rectangle keys x queries (Packed blocks).
+    Returns minbuf fp32-bits [nk, nq*P] (and minbuf_t [nq, nk*P] when two_way).  keys is queries (same
+    buffers): the symmetric case - upper-triangle tiles only, optionally the part-th of nparts slices."""
+    nk, nq, P, D = keys.n, queries.n, keys.P, keys.D
+    if queries.P != P or queries.D != D:
+        raise ValueError("key / query blocks disagree on the patch shape")
+    dev = keys.hl.device
+    same = keys.hl.data_ptr() == queries.hl.data_ptr() and nk == nq
+    if same and two_way:
+        raise ValueError("keys == queries is the symmetric case, not a two-way block")
+    minbuf = torch.full((nk, nq * P), INF_BITS, dtype=torch.int32, device=dev)
+    minbuf_t = torch.full((nq, nk * P), INF_BITS, dtype=torch.int32, device=dev) if two_way else None
+    ev0, ev1 = _event_pair()
+    _check(lib().ac_pair_min_sq_packed(keys.hl.data_ptr(), keys.sq.data_ptr(), nk, queries.hl.data_ptr(),
+                                       queries.sq.data_ptr(), nq, P, D, minbuf.data_ptr(),
+                                       minbuf_t.data_ptr() if two_way else None, part, nparts, _stream()))
+    if ev0 is not None:
+        ev1.record()
+        # ordered image pairs this launch resolves: both directions of a symmetric / two-way block
+        pairs = (nk * (nk - 1.0) / nparts) if same else (2.0 * nk * nq if two_way else 1.0 * nk * nq)
+        kernel_events.append(("pair_min_sq", ev0, ev1, pairs, P, D))
+    return (minbuf, minbuf_t) if two_way else minbuf
+
+
+def pair_accumulate(minbuf, P, reduce, self_first, shift, acc):
+    """Fold minbuf [nk, ncols] (rows may be strided) into acc (a slice of new_acc()'s tensor)."""
+    nk, ncols = minbuf.shape
+    if minbuf.stride(1) != 1:
+        raise ValueError("minbuf columns must be contiguous")
+    if acc.numel() != ncols or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous slice of %d columns" % ncols)
+    if nk == 0 or ncols == 0:
+        return
+    _check(lib().ac_pair_accumulate(minbuf.data_ptr(), nk, minbuf.stride(0), ncols, P, reduce, int(self_first),
+                                    shift.data_ptr() if shift is not None else None, acc.data_ptr(), _stream()))
+
+
+def pair_finalize(acc, P, reduce, count, shift):
+    """acc [n*P] -> w fp32 [n, P]."""
+    ncols = acc.numel()
+    w = torch.empty((ncols // P, P), dtype=torch.float32, device=acc.device)
+    if ncols:
+        _check(lib().ac_pair_finalize(acc.data_ptr(), ncols, reduce, int(count),
+                                      shift.data_ptr() if shift is not None else None, w.data_ptr(), _stream()))
+    return w
 
 
 def pair_min_dist_staged(Zq, Zk, reduce, self_offset=0, minbuf_budget=1 << 30):
-    """Same result as pair_min_dist, composed from the staged entry points (pack once, one MFMA
-    launch per query chunk, reduce).  When `kernel_events` is a list, each MFMA launch is bracketed
-    by events recorded on the launch stream (bench.py's roofline leg reads them)."""
+    """Same result as pair_min_dist, composed from the staged entry points (pack once, one MFMA launch per
+    query chunk, accumulate, finalize)."""
     pq, pk = _dev(Zq, torch.float32, "Zq"), _dev(Zk, torch.float32, "Zk")
     nq, P, D = Zq.shape
     nk = Zk.shape[0]
     if Zk.shape[1:] != Zq.shape[1:]:
         raise ValueError("Zq / Zk patch shapes differ: %s vs %s" % (tuple(Zq.shape), tuple(Zk.shape)))
-    hk, sk = pack_hl32(Zk.reshape(nk * P, D), want_sqnorm=True)
+    keys = pack_images(Zk)
     if pq == pk and nq == nk:
-        hq, sq = hk, sk
+        queries = keys
     elif pk <= pq < pk + Zk.numel() * 4 and (pq - pk) % (P * D * 4) == 0 and pq + Zq.numel() * 4 <= pk + Zk.numel() * 4:
         first = (pq - pk) // (P * D * 4)                      # the query shard is a slice of the key set
-        hq, sq = hk[first * P:(first + nq) * P], sk[first * P:(first + nq) * P]
+        queries = keys.slice(first, first + nq)
     else:
-        hq, sq = pack_hl32(Zq.reshape(nq * P, D), want_sqnorm=True)
+        queries = pack_images(Zq)
+    mean = reduce == REDUCE_MEAN_OTHERS
+    shift = fixed_shift(max_sq([keys] if queries is keys else [keys, queries], Zq.device), nk) if mean else None
+    acc = new_acc(nq * P, reduce, Zq.device)
     chunk = max(1, min(nq, minbuf_budget // (nk * P * 4)))
-    w = torch.empty((nq, P), dtype=torch.float32, device=Zq.device)
-    minbuf = torch.empty((nk, chunk * P), dtype=torch.int32, device=Zq.device)
-    st = _stream()
     for q0 in range(0, nq, chunk):
         qn = min(chunk, nq - q0)
-        mb = minbuf.view(-1)[: nk * qn * P]
-        mb.fill_(0x7f800000)
-        if kernel_events is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        _check(lib().ac_pair_min_sq_packed(hk.data_ptr(), sk.data_ptr(), nk, hq[q0 * P:].data_ptr(),
-                                           sq[q0 * P:].data_ptr(), qn, P, D, mb.data_ptr(), 0, 1, st))
-        if kernel_events is not None:
-            ev1.record()
-            kernel_events.append(("pair_min_sq", ev0, ev1, nk, qn, P, D))
-        _check(lib().ac_pair_reduce(mb.data_ptr(), nk, qn, P, reduce, self_offset + q0, w[q0:].data_ptr(), st))
-    return w
+        qs = queries if (qn == nq and queries is keys) else queries.slice(q0, q0 + qn)
+        mb = pair_block(keys, qs)
+        pair_accumulate(mb, P, reduce, self_offset + q0, shift, acc[q0 * P:(q0 + qn) * P])
+    inside = 0 <= self_offset and self_offset + nq <= nk
+    return pair_finalize(acc, P, reduce, nk - 1 if (mean and inside) else nk, shift)
 
 
 def pair_min_sq_part(Z, part=0, nparts=1):
@@ -327,32 +463,29 @@ def pair_min_sq_part(Z, part=0, nparts=1):
     minbuf fp32 [N, N*P] with minbuf[j][i*P + p] = min_q ||Z[i][p] - Z[j][q]||^2 for the (i, j) tile
     pairs of this slice and +inf elsewhere.  The element-wise minimum over all `nparts` slices (e.g.
     a MIN all-reduce across ranks) is the complete matrix; `pair_reduce` turns it into w."""
-    _dev(Z, torch.float32, "Z")
-    N, P, D = Z.shape
-    hk, sk = pack_hl32(Z.reshape(N * P, D), want_sqnorm=True)
-    minbuf = torch.full((N, N * P), float("inf"), dtype=torch.float32, device=Z.device)
-    if kernel_events is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    _check(lib().ac_pair_min_sq_packed(hk.data_ptr(), sk.data_ptr(), N, hk.data_ptr(), sk.data_ptr(), N, P, D,
-                                       minbuf.data_ptr(), part, nparts, _stream()))
-    if kernel_events is not None:
-        ev1.record()
-        kernel_events.append(("pair_min_sq", ev0, ev1, N, N / float(nparts), P, D))
-    return minbuf
+    pk = pack_images(Z)
+    return pair_block(pk, pk, part=part, nparts=nparts).view(torch.float32)
 
 
-def pair_reduce(minbuf, P, reduce, self_first=0):
+def pair_reduce(minbuf, P, reduce, self_first=0, max_sq_t=None, n_keys=None):
     """minbuf fp32 [nk, nq*P] (squared mins) -> w fp32 [nq, P]: mean over key images != self_first + i
-    of the square roots, or the square root of the min over all key images."""
-    p = _dev(minbuf, torch.float32, "minbuf")
+    of the square roots, or the square root of the min over all key images.  The fixed-point scale of the
+    mean comes from max_sq_t (fp32 [1], the category's largest squared norm); without it the bound is taken
+    from the minbuf itself (d <= sqrt(max d2))."""
     nk, cols = minbuf.shape
     nq = cols // P
-    w = torch.empty((nq, P), dtype=torch.float32, device=minbuf.device)
     if nq == 0:                      # a rank with an empty image shard
-        return w
-    _check(lib().ac_pair_reduce(p, nk, nq, P, reduce, self_first, w.data_ptr(), _stream()))
-    return w
+        return torch.empty((0, P), dtype=torch.float32, device=minbuf.device)
+    bits = minbuf.view(torch.int32)
+    shift = None
+    if reduce == REDUCE_MEAN_OTHERS:
+        if max_sq_t is None:         # d <= sqrt(max d2) = 2 sqrt(max d2 / 4)
+            max_sq_t = (minbuf.view(torch.float32).max().reshape(1) / 4).contiguous()
+        shift = fixed_shift(max_sq_t, n_keys if n_keys is not None else nk)
+    acc = new_acc(cols, reduce, minbuf.device)
+    pair_accumulate(bits, P, reduce, self_first, shift, acc)
+    inside = 0 <= self_first and self_first + nq <= nk
+    return pair_finalize(acc, P, reduce, nk - 1 if (reduce == REDUCE_MEAN_OTHERS and inside) else nk, shift)
 
 
 def alpha_softmax(w, tau, k=1.0):

@@ -19,6 +19,7 @@ torchvision is absent and ``$AC_BACKBONE_SEED`` is set, a seeded WRN50-SHAPED st
 CPU/CLI path of config 1, NOT part of the MI355X hot path.  The other torchvision/timm names raise.
 """
 import os
+import sys
 
 import torch
 
@@ -56,7 +57,7 @@ def load(name):
         from patchcore import standin_cnn
         seed = _seed_opt_in(name)
         print("WARNING: backbone %r is a seeded WRN50-SHAPED stand-in (seed %d), not torchvision's pretrained "
-              "wide_resnet50_2: plumbing only" % (name, seed))
+              "wide_resnet50_2: plumbing only" % (name, seed), file=sys.stderr)
         model = standin_cnn.wrn50_shaped(seed)
         model.weights_source = "standin-random-init(seed=%d)" % seed
         return model
@@ -74,7 +75,8 @@ def load(name):
         seed = _seed_opt_in(name)
         torch.manual_seed(seed)
         source = "random-init(seed=%d)" % seed
-        print("WARNING: backbone %r runs on SEEDED RANDOM weights (%s), not the DINO checkpoint" % (name, source))
+        print("WARNING: backbone %r runs on SEEDED RANDOM weights (%s), not the DINO checkpoint" % (name, source),
+              file=sys.stderr)
     model = vits.vit_base(patch_size=patch_size, num_classes=0)
     for p in model.parameters():
         p.requires_grad = False

@@ -85,6 +85,30 @@ def best_map(L1, L2):
     return out
 
 
+def metrics_from_labels(label, predict):
+    predict = best_map(label, predict).astype(int)
+    NMI = metrics.normalized_mutual_info_score(label, predict)
+    ARI = metrics.adjusted_rand_score(label, predict)
+    F1 = metrics.f1_score(label, predict, average="micro")
+    return NMI, ARI, F1, label, predict
+
+
+def cluster_metrics_from_pdist(condensed, anomaly_names):
+    """The same chain from distances that are already computed (bench.py, pipeline output): condensed float64
+    Euclidean distances of ALL images (tensor or array) + per-image anomaly strings.  "combined" images are
+    dropped by selecting the sub-matrix (distances between the kept images do not change)."""
+    from scipy.spatial.distance import squareform
+    d = condensed.detach().cpu().numpy() if isinstance(condensed, torch.Tensor) else np.asarray(condensed)
+    keep = [i for i, a in enumerate(anomaly_names) if a != "combined"]
+    names = [anomaly_names[i] for i in keep]
+    if len(keep) != len(anomaly_names):
+        d = squareform(squareform(d, checks=False)[np.ix_(keep, keep)], checks=False)
+    label = LabelEncoder().fit_transform(names).astype(int)
+    n = len(keep)
+    predict = cut_tree(ward_children(d, n), len(set(label)), n) if n > 1 else np.zeros(n, dtype=np.intp)
+    return metrics_from_labels(label, predict)
+
+
 def cluster_metrics(X, anomaly_names, device=None):
     """Reference :176-220 from (X, per-image anomaly strings): drop "combined", Ward with
     k = #labels, best_map, NMI / ARI / micro-F1.  Returns NMI, ARI, F1, label, predict."""
@@ -93,8 +117,4 @@ def cluster_metrics(X, anomaly_names, device=None):
     Xk = np.asarray(X)[keep]
     label = LabelEncoder().fit_transform(names).astype(int)
     predict = agglomerative_ward(Xk, len(set(label)), device)
-    predict = best_map(label, predict).astype(int)
-    NMI = metrics.normalized_mutual_info_score(label, predict)
-    ARI = metrics.adjusted_rand_score(label, predict)
-    F1 = metrics.f1_score(label, predict, average="micro")
-    return NMI, ARI, F1, label, predict
+    return metrics_from_labels(label, predict)

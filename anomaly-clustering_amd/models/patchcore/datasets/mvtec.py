@@ -96,6 +96,45 @@ class MVTecDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data_to_iterate)
 
+    def load_category(self, device, batch_size=64):
+        """ONE pass over the split for the MI355X pipeline (the reference walks the dataset twice with batch size 1:
+        once for the per-image records, examples/main.py:254-262, once to embed, :266): every file is decoded once
+        on the host (PIL), the uint8 pixels of equally sized images go to the device in batches and the whole
+        transform chain runs there (acnative.preprocess_images: bit-identical to transform_img).
+        Returns (images fp32 [N, 3, S, S] on `device`, info) with info[i] = the item dict without pixels, in the
+        form DataLoader(batch_size=1) collates it (what examples/test.py reads)."""
+        import PIL.Image
+        import acnative
+        n = len(self.data_to_iterate)
+        size = self.imagesize[1]
+        images = torch.empty((n, 3, size, size), dtype=torch.float32, device=device)
+        info = []
+        pending, shape = [], None
+
+        def flush():
+            if not pending:
+                return
+            idx = [i for i, _ in pending]
+            u8 = torch.from_numpy(np.stack([a for _, a in pending])).to(device, non_blocking=True)
+            out = acnative.preprocess_images(u8, self.resize, size, IMAGENET_MEAN, IMAGENET_STD)
+            if idx == list(range(idx[0], idx[0] + len(idx))):
+                images[idx[0]: idx[0] + len(idx)] = out
+            else:
+                images[torch.tensor(idx, device=device)] = out
+            pending.clear()
+
+        for i, (classname, anomaly, image_path, _mask) in enumerate(self.data_to_iterate):
+            arr = np.asarray(PIL.Image.open(image_path).convert("RGB"))
+            if shape is not None and (arr.shape != shape or len(pending) >= batch_size):
+                flush()
+            shape = arr.shape
+            pending.append((i, arr))
+            info.append({"classname": [classname], "anomaly": [anomaly],
+                         "is_anomaly": torch.tensor([int(anomaly != "good")]),
+                         "image_name": ["/".join(image_path.split("/")[-4:])], "image_path": [image_path]})
+        flush()
+        return images, info
+
     def get_image_data(self):
         per_class, masks = {}, {}
         for classname in self.classnames_to_use:

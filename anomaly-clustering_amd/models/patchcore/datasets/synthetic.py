@@ -92,6 +92,17 @@ class SyntheticMVTecDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.anomalies)
 
+    def load_category(self, device, batch_size=64):
+        """Same contract as MVTecDataset.load_category: (images on `device`, per-image records as collated by a
+        batch-size-1 DataLoader) from one pass."""
+        info = []
+        for idx in range(len(self)):
+            item = self[idx]
+            info.append({"classname": [item["classname"]], "anomaly": [item["anomaly"]],
+                         "is_anomaly": torch.tensor([item["is_anomaly"]]), "image_name": [item["image_name"]],
+                         "image_path": [item["image_path"]]})
+        return self.images.to(device), info
+
     def __getitem__(self, idx):
         anomaly = self.anomalies[idx]
         name = "%s/%s/%s/%03d.png" % (self.classname, self.split.value, anomaly, idx)

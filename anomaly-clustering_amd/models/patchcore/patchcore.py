@@ -115,16 +115,26 @@ class AnomalyClusteringCore(torch.nn.Module):
     @torch.no_grad()
     def embed_device(self, images, batch_size=32):
         """Batched, device-resident embedding: images [N, 3, H, W] (any device) -> Z [N, P, D] fp32
-        on self.device.  This is what the MI355X pipeline (examples/main.py, bench.py) uses."""
-        chunks = []
-        for s in range(0, images.shape[0], batch_size):
+        on self.device.  This is what the MI355X pipeline (examples/main.py, bench.py) uses.  Z is allocated
+        once and every batch's aggregation kernel writes its rows in place (no concatenation copy)."""
+        N = images.shape[0]
+        Z = None
+        for s in range(0, N, batch_size):
             chunk = images[s:s + batch_size].to(self.device, dtype=torch.float32, non_blocking=True)
-            z = self._embed(chunk, None, detach=False)
-            chunks.append(z.reshape(chunk.shape[0], -1, z.shape[-1]))
-        return torch.cat(chunks, dim=0) if len(chunks) > 1 else chunks[0]
+            if Z is None:
+                z = self._embed(chunk, None, detach=False)
+                rows = z.shape[0] // chunk.shape[0]
+                if chunk.shape[0] == N:
+                    return z.reshape(N, rows, z.shape[-1])
+                Z = torch.empty((N, rows, z.shape[-1]), dtype=torch.float32, device=self.device)
+                Z[: chunk.shape[0]] = z.reshape(chunk.shape[0], rows, -1)
+            else:
+                self._embed(chunk, None, detach=False, out=Z[s:s + chunk.shape[0]])
+        return Z
 
-    def _embed(self, images, supervised, detach=True, provide_patch_shapes=False):
-        """Reference :355-431.  `supervised` is accepted and ignored, as upstream."""
+    def _embed(self, images, supervised, detach=True, provide_patch_shapes=False, out=None):
+        """Reference :355-431.  `supervised` is accepted and ignored, as upstream.  out (extension): a
+        contiguous fp32 device tensor the rows of Z are written into."""
         _ = self.forward_modules["feature_aggregator"].eval()
         with torch.no_grad():
             taps = self.forward_modules["feature_aggregator"](images)
@@ -132,7 +142,7 @@ class AnomalyClusteringCore(torch.nn.Module):
             Z, patch_shapes = acnative.patch_aggregate(
                 feats, self.patch_maker.patchsize,
                 self.forward_modules["preprocessing"].output_dim,
-                self.forward_modules["preadapt_aggregator"].target_dim)
+                self.forward_modules["preadapt_aggregator"].target_dim, out=out)
         out = [x.detach().cpu().numpy() for x in Z] if detach else Z
         if provide_patch_shapes:
             return out, patch_shapes

@@ -1,21 +1,48 @@
 """One category end to end on one or several MI355X: extract -> aggregate -> alpha -> weighted
 average -> (all-gather) -> pairwise distance.  This is the layer the reference does not have
 (SURVEY.md 2.2): the reference runs ``make_category_data`` (examples/main.py:183-311) on a single
-device with batch size 1; here the images of a category are sharded over the ranks of a
-``torch.distributed`` process group (backend "nccl" = RCCL over xGMI on ROCm).
+device with batch size 1 and walks all N(N-1) ordered image pairs one ``cdist`` at a time
+(models/patchcore/utils.py:222-237); here the images of a category are sharded over the ranks of a
+``torch.distributed`` process group (backend "nccl" = RCCL over xGMI on ROCm) and the pair loop
+becomes a block schedule over packed (split-fp16) image blocks.
 
 Per rank r of G (contiguous image block [lo_r, hi_r)):
-    Z_r   = embed(images[lo_r:hi_r])                      no communication
-    Z     = all_gather(Z_r)                               RCCL all-gather of the patch embeddings
-    w_r   = pair_min_dist(Z_r, Z, self_offset=lo_r)       local queries x all keys (MFMA)
-    a_r   = softmax(w_r / tau)  (fp64);  X_r = a_r . Z_r  no communication
-    X, a  = all_gather(X_r), all_gather(a_r)              the all-gather north_star names
-    d     = pdist(X)                                      rank 0
-Supervised mode replaces the key set by the (sharded, all-gathered) normal-image bank.
+    Z_r      = embed(images[lo_r:hi_r])                   no communication
+    pk_r     = pack(Z_r)                                  hl32 image + squared norms, ONCE, local shard only
+    w_r      = alpha_weights(...)                         the block schedule below (MFMA)
+    a_r      = softmax(w_r / tau)  (fp64);  X_r = a_r . Z_r      no communication
+    X, a     = all_gather(X_r), all_gather(a_r)           the all-gather north_star names
+    d        = pdist(X)                                   rank 0
+
+Unsupervised weights: w_i[p] = mean_{j != i} min_q |Z_i[p] - Z_j[q]|.  d(i,j) block = d(j,i) block
+transposed, so every UNORDERED pair of image blocks is multiplied once and reduced in both directions
+(half the MFMA work of "my queries x all keys").  Two schedules:
+
+  "slices" (N^2 * P * 4 bytes <= budget, every MVTec category): the packed shards are all-gathered
+      (one RCCL all-gather of hl32 + norms: N = 167 -> 2.1 GB), each rank runs slice r/G of the folded
+      upper-triangle tile space of the whole N*P x N*P problem into its own [N, N*P] matrix of minima,
+      one MIN all-reduce (N = 167: 87 MB) completes it.  Perfectly balanced at any N.
+  "ring" (anything larger, e.g. N = 10 000): nothing is gathered.  Rank r keeps its shard resident and
+      receives the shard of rank r+k at ring step k = 1 .. G/2 into a double buffer (the transfer of step
+      k+1 runs under the MFMA work of step k); it multiplies (its shard) x (that shard) two-way, in
+      sub-blocks of c x c images sized to the minbuf budget, and for even G the step k = G/2 block is split
+      between its two owners.  Sums for the other rank's queries go into the same [N*P] int64 accumulator;
+      ONE all-reduce(SUM) of it at the end hands every rank its complete sums.  Per-GPU bytes at N = 10 000,
+      G = 8, P = 784, D = 4096: Z fp32 16 GB + hl32 16 GB + 2 x 16 GB receive buffers + 2 x 1 GiB minbuf
+      + 63 MB accumulator = 66 GB of 288.
+
+The sum over key images is kept in 64-bit fixed point (csrc/alpha.hip), so both schedules, any rank count
+and any block size give bit-identical w for the same Z.  On one GPU the ring schedule degenerates to
+"sub-blocks of my own shard" - that is how N = 2 000+ runs in a fixed memory budget.
+
+Supervised weights (min over the normal-image bank): the bank is sharded like the images, each rank
+packs its share, and the G bank shards go round the same ring, one-way blocks (local queries x that
+shard), min into a uint32 accumulator; no collective at the end.
 
 `ops` is the compute seam: by default the HIP library (acnative + AnomalyClusteringCore); the
-world-size-2 gloo tests substitute a CPU stand-in to exercise the sharding and collectives.
+world-size-2 gloo tests substitute a CPU stand-in to exercise the schedules and collectives.
 """
+import math
 import time
 
 import numpy as np
@@ -23,13 +50,57 @@ import torch
 import torch.distributed as dist
 
 
-SYMMETRIC_MINBUF_BYTES = 1 << 30     # largest [N, N*P] fp32 matrix the partitioned symmetric path may allocate
+MINBUF_BYTES = 1 << 30        # largest matrix of minima one launch may fill (x2 for a two-way block)
+MEAN, MIN = 0, 1              # acnative.REDUCE_MEAN_OTHERS / REDUCE_MIN_ALL
+NO_SELF = -(1 << 62)
 
 
 def shard_bounds(n, world):
     """Contiguous blocks of ceil(n/world) images: [(lo, hi)] per rank (trailing ranks may be empty)."""
     per = (n + world - 1) // world if world > 0 else n
     return [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+
+
+def block_images(P, budget=MINBUF_BYTES):
+    """Largest c with a c x c-image matrix of minima (c * c * P fp32) inside the budget."""
+    return max(1, int(math.isqrt(max(1, budget // (4 * P)))))
+
+
+def _subranges(lo, hi, c):
+    return [(a, min(hi, a + c)) for a in range(lo, hi, c)]
+
+
+def unsup_schedule(bounds, rank, c):
+    """The unsupervised block schedule of one rank, in GLOBAL image indices.  Yields
+         ("sym", step, (a0, a1))              keys = queries = images [a0, a1): symmetric launch
+         ("two", step, (a0, a1), (b0, b1))     keys = [a0, a1), queries = [b0, b1): two-way launch
+       step 0 touches only the rank's own shard; step k >= 1 needs the shard of rank (rank + k) % world,
+       which holds the block that is not the rank's own.  Over all ranks every unordered pair of distinct
+       images is covered exactly once (tests/test_host_logic.py checks that for many shapes)."""
+    world = len(bounds)
+    lo, hi = bounds[rank]
+    subs = _subranges(lo, hi, c)
+    for ia, a in enumerate(subs):
+        yield ("sym", 0, a)
+        for b in subs[ia + 1:]:
+            yield ("two", 0, a, b)
+    for k in range(1, world // 2 + 1):
+        src = (rank + k) % world
+        slo, shi = bounds[src]
+        mine, theirs = (lo, hi), (slo, shi)
+        if 2 * k == world:
+            # the pair {rank, src} meets from both sides at this step: the lower rank takes the first half of
+            # ITS images against all of the higher rank's, the higher rank the remaining images of the lower
+            low, high = min(rank, src), max(rank, src)
+            llo, lhi = bounds[low]
+            mid = llo + (lhi - llo + 1) // 2
+            if rank == low:
+                mine = (llo, mid)
+            else:
+                theirs = (mid, lhi)
+        for a in _subranges(mine[0], mine[1], c):
+            for b in _subranges(theirs[0], theirs[1], c):
+                yield ("two", k, a, b)
 
 
 class HipOps:
@@ -52,16 +123,30 @@ class HipOps:
         self._zshape = tuple(Z.shape[1:])
         return Z
 
-    def pair_min_dist(self, Zq, Zk, reduce, self_offset):
-        if Zq.shape[0] == 0:
-            return torch.empty((0, Zq.shape[1]), dtype=torch.float32, device=Zq.device)
-        return self.acnative.pair_min_dist_staged(Zq, Zk, reduce, self_offset)
+    # ---- packed blocks and the pair kernels (see acnative for the semantics)
+    def pack(self, Z):
+        return self.acnative.pack_images(Z)
 
-    def pair_min_sq_part(self, Z, part, nparts):
-        return self.acnative.pair_min_sq_part(Z, part, nparts)
+    def empty_packed(self, n, like):
+        return self.acnative.Packed.empty(n, like.P, like.D, like.hl.device)
 
-    def pair_reduce(self, minbuf, P, reduce, self_first):
-        return self.acnative.pair_reduce(minbuf, P, reduce, self_first)
+    def max_sq(self, packed_list, device):
+        return self.acnative.max_sq(packed_list, device)
+
+    def fixed_shift(self, max_sq_t, n_keys):
+        return self.acnative.fixed_shift(max_sq_t, n_keys)
+
+    def new_acc(self, ncols, reduce, device):
+        return self.acnative.new_acc(ncols, reduce, device)
+
+    def pair_block(self, keys, queries, two_way=False, part=0, nparts=1):
+        return self.acnative.pair_block(keys, queries, two_way, part, nparts)
+
+    def pair_accumulate(self, minbuf, P, reduce, self_first, shift, acc):
+        self.acnative.pair_accumulate(minbuf, P, reduce, self_first, shift, acc)
+
+    def pair_finalize(self, acc, P, reduce, count, shift):
+        return self.acnative.pair_finalize(acc, P, reduce, count, shift)
 
     def alpha_softmax(self, w, tau, k):
         return self.acnative.alpha_softmax(w, tau, k)
@@ -84,7 +169,9 @@ def _world(group):
 
 def all_gather_rows(local, counts, group=None):
     """Concatenate per-rank row blocks of unequal length (counts[r] rows on rank r) on every rank.
-    Pads to the largest block so one all_gather_into_tensor (one RCCL all-gather) moves everything."""
+    Pads to the largest block so one all_gather_into_tensor (one RCCL all-gather) moves everything.  With
+    shard_bounds' layout (every non-empty shard but the last is full) the first sum(counts) rows of the
+    receive buffer ARE the concatenation - no second copy."""
     rank, world = _world(group)
     if world == 1:
         return local
@@ -96,8 +183,12 @@ def all_gather_rows(local, counts, group=None):
         send[: local.shape[0]] = local
     recv = torch.empty((world * cap,) + tuple(tail), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
-    if all(c == cap for c in counts):
-        return recv
+    total = sum(counts)
+    full = 0
+    while full < world and counts[full] == cap:
+        full += 1
+    if all(c == 0 for c in counts[full + 1:]):       # [cap]*full + [short] + [0]*rest: already contiguous
+        return recv[:total]
     return torch.cat([recv[r * cap: r * cap + counts[r]] for r in range(world)], dim=0)
 
 
@@ -110,11 +201,155 @@ def select_bank(n_train, n_test, train_ratio, seed=0):
     return torch.randperm(n_train, generator=g)[:m]
 
 
+# ------------------------------------------------------------------ the ring of packed shards
+class _Ring:
+    """Shard exchange of the ring schedule: at step k every rank sends its own packed shard to rank - k and
+    receives the shard of rank + k into one of two buffers.  prefetch(k) posts the transfer, get(k) waits
+    for it (the wait is a stream dependency under RCCL) - posting step k+1 before computing step k overlaps
+    the transfer with the MFMA work.  Under a host backend (gloo: the CPU tests, and the tests that run two
+    ranks on ONE GPU, which RCCL refuses) device tensors are staged through host memory."""
+
+    def __init__(self, ops, local, sizes, rank, world, group):
+        self.ops, self.local, self.sizes, self.rank, self.world, self.group = ops, local, sizes, rank, world, group
+        self.cap = max(sizes) if sizes else 0
+        self.bufs = [None, None]
+        self.pending = {}
+        self.stage = world > 1 and dist.get_backend(group) != "nccl" and local.tensors()[0].is_cuda
+        self._host_local = None
+
+    def _peer(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def prefetch(self, k):
+        if k in self.pending or k <= 0 or k >= self.world:
+            return
+        src, dst = (self.rank + k) % self.world, (self.rank - k) % self.world
+        n_src = self.sizes[src]
+        slot = k & 1
+        if self.bufs[slot] is None and n_src:
+            self.bufs[slot] = self.ops.empty_packed(self.cap, self.local)
+        recv = self.bufs[slot].slice(0, n_src) if n_src else None
+        send_t = self.local.tensors() if self.local.n else []          # an empty shard is neither sent nor received
+        recv_t = recv.tensors() if n_src else []
+        host_recv = None
+        if self.stage:
+            if self._host_local is None:
+                self._host_local = [t.cpu() for t in send_t]
+            send_t = self._host_local
+            host_recv = [torch.empty(t.shape, dtype=t.dtype) for t in recv_t]
+        p2p = [dist.P2POp(dist.isend, t, self._peer(dst), self.group) for t in send_t]
+        p2p += [dist.P2POp(dist.irecv, t, self._peer(src), self.group) for t in (host_recv if self.stage else recv_t)]
+        works = dist.batch_isend_irecv(p2p) if p2p else []
+        self.pending[k] = (works, recv, host_recv)
+
+    def get(self, k):
+        self.prefetch(k)
+        works, recv, host_recv = self.pending.pop(k)
+        for w in works:
+            w.wait()
+        if host_recv is not None:
+            for d, h in zip(recv.tensors() if recv is not None else [], host_recv):
+                d.copy_(h)
+        return recv
+
+
+def _slice_global(pk, base, rng):
+    return pk.slice(rng[0] - base, rng[1] - base)
+
+
+def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto"):
+    """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard)."""
+    n = bounds[-1][1]
+    lo, hi = bounds[rank]
+    P = pk_loc.P
+    counts = [b - a for a, b in bounds]
+    if schedule == "auto":
+        schedule = "slices" if (world > 1 and n * n * P * 4 <= budget) else "ring"
+    if schedule == "slices":
+        rows = [c * P for c in counts]
+        hl = all_gather_rows(pk_loc.hl, rows, group)
+        sq = all_gather_rows(pk_loc.sq, rows, group)
+        pk_all = type(pk_loc)(hl, sq, n, P, pk_loc.D)
+        shift = ops.fixed_shift(ops.max_sq([pk_all], device), n)
+        minbuf = ops.pair_block(pk_all, pk_all, part=rank, nparts=world)          # [N, N*P], +inf outside the slice
+        if world > 1:
+            mf = minbuf.view(torch.float32)
+            dist.all_reduce(mf, op=dist.ReduceOp.MIN, group=group)
+        acc = ops.new_acc((hi - lo) * P, MEAN, device)
+        ops.pair_accumulate(minbuf[:, lo * P: hi * P], P, MEAN, lo, shift, acc)
+        return ops.pair_finalize(acc, P, MEAN, n - 1, shift)
+
+    m = ops.max_sq([pk_loc], device)
+    if world > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    shift = ops.fixed_shift(m, n)
+    acc = ops.new_acc(n * P, MEAN, device)                 # sums for EVERY image: remote queries' parts too
+    c = block_images(P, budget)
+    ring = _Ring(ops, pk_loc, counts, rank, world, group)
+    by_step = {}
+    for item in unsup_schedule(bounds, rank, c):
+        by_step.setdefault(item[1], []).append(item)
+    ring.prefetch(1)
+    for step in range(0, world // 2 + 1):
+        remote, rbase = None, 0
+        if step > 0:                                       # every rank takes part in every exchange, work or not
+            remote = ring.get(step)
+            rbase = bounds[(rank + step) % world][0]
+            if step + 1 <= world // 2:
+                ring.prefetch(step + 1)
+        for item in by_step.get(step, []):
+            if item[0] == "sym":
+                a = item[2]
+                A = _slice_global(pk_loc, lo, a)
+                mb = ops.pair_block(A, A)
+                ops.pair_accumulate(mb, P, MEAN, 0, shift, acc[a[0] * P: a[1] * P])
+            else:
+                a, b = item[2], item[3]
+                A = _slice_global(pk_loc, lo, a)
+                B = _slice_global(pk_loc, lo, b) if step == 0 else _slice_global(remote, rbase, b)
+                if a[0] > b[0]:        # canonical orientation: the block with the LOWER image indices is the row
+                    a, b, A, B = b, a, B, A   # operand, whichever rank computes it (a.b and b.a differ in the last bit)
+                mb, mbt = ops.pair_block(A, B, two_way=True)
+                ops.pair_accumulate(mb, P, MEAN, NO_SELF, shift, acc[b[0] * P: b[1] * P])     # keys A, queries B
+                ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[a[0] * P: a[1] * P])    # keys B, queries A
+    if world > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return ops.pair_finalize(acc[lo * P: hi * P], P, MEAN, n - 1, shift)
+
+
+def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES):
+    """w fp32 [n_loc, P]: min over every bank image (utils.py:230-237 for every i of the shard).  The bank
+    shards go round the ring; each is multiplied one-way against the local queries, in sub-blocks."""
+    P = pk_loc.P
+    n_loc = pk_loc.n
+    acc = ops.new_acc(n_loc * P, MIN, device)
+    counts = [b - a for a, b in bank_bounds]
+    ring = _Ring(ops, pk_bank_loc, counts, rank, world, group)
+    ring.prefetch(1)
+    c = block_images(P, budget)
+    for k in range(world):
+        keys = pk_bank_loc if k == 0 else ring.get(k)
+        if k + 1 < world:
+            ring.prefetch(k + 1)
+        if keys is None or keys.n == 0 or n_loc == 0:
+            continue
+        for q0, q1 in _subranges(0, n_loc, c):
+            Q = pk_loc.slice(q0, q1)
+            for k0, k1 in _subranges(0, keys.n, c):
+                mb = ops.pair_block(keys.slice(k0, k1), Q)
+                ops.pair_accumulate(mb, P, MIN, NO_SELF, None, acc[q0 * P: q1 * P])
+    m = sum(counts)
+    return ops.pair_finalize(acc, P, MIN, m, None)
+
+
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
-                 group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None):
+                 group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
+                 schedule="auto"):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
+    budget / schedule: memory budget of one matrix of minima and the unsupervised schedule ("auto", "slices",
+    "ring") - results do not depend on either.
     Returns dict(alpha fp32 [N, 1, P] on device, X float32 ndarray [N, D], X_dev, pdist (rank 0), bounds)."""
     rank, world = _world(group)
     n = images.shape[0]
@@ -131,6 +366,7 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     t0 = time.perf_counter()
     Z_loc = ops.embed(images[lo:hi])                                   # [n_loc, P, D]
     mark("embed", t0)
+    device = Z_loc.device
 
     t0 = time.perf_counter()
     if supervised == "supervised":
@@ -140,20 +376,10 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         bb = shard_bounds(len(sel), world)
         blo, bhi = bb[rank]
         bank_loc = ops.embed(train_images[sel[blo:bhi]])
-        bank = all_gather_rows(bank_loc, [b - a for a, b in bb], group)
-        w_loc = ops.pair_min_dist(Z_loc, bank, 1, 0)
+        w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget)
+        del bank_loc
     elif supervised == "unsupervised":
-        Z_all = all_gather_rows(Z_loc, counts, group)
-        P = Z_all.shape[1]
-        if world > 1 and n * n * P * 4 <= SYMMETRIC_MINBUF_BYTES:
-            # every rank takes 1/world of the UPPER-TRIANGLE tiles of the symmetric N*P x N*P problem
-            # (each tile reduced in both directions), then one MIN all-reduce of the [N, N*P] matrix of
-            # per-(key image, query patch) minima completes it: half the MFMA work of "my queries x all keys"
-            minbuf = ops.pair_min_sq_part(Z_all, rank, world)
-            dist.all_reduce(minbuf, op=dist.ReduceOp.MIN, group=group)
-            w_loc = ops.pair_reduce(minbuf[:, lo * P: hi * P].contiguous(), P, 0, lo)
-        else:
-            w_loc = ops.pair_min_dist(Z_loc, Z_all, 0, lo)
+        w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule)
     else:                                                              # "average" (main.py:290-291)
         w_loc = None
     mark("pair_min_dist", t0)
@@ -184,4 +410,5 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     out = dict(by_tau[float(taus[0])])
     out["bounds"] = bounds
     out["by_tau"] = by_tau
+    out["w_loc"] = w_loc
     return out

@@ -1,27 +1,41 @@
 #!/usr/bin/env python3
 """End-to-end images/sec of the anomaly-clustering hot path on N MI355X of one node.
 
-A *step* = one MVTec-AD-shaped category through the whole hot path with the images already in
-HBM:  ViT-B/8 extract (blocks.10/11) -> patch aggregation -> unsupervised alpha (tau=1) ->
-weighted-average embeddings -> (RCCL all-gather) -> N x N pairwise distance.  Because alpha is
-O(N^2), every images/sec figure is tied to the category size; the default is BASELINE.json
-configs[1] with the "bottle" test set (N=83) and random-init ViT-B/8 weights (no checkpoint
-or dataset is reachable offline).  With --gpus G the same category is sharded over G ranks
-(strong scaling; Z and X are all-gathered over RCCL).
+A *step* = one pass of the workload through the whole hot path with the images already in HBM:
+ViT-B/8 extract (blocks.10/11) -> patch aggregation -> alpha weights -> weighted-average embeddings ->
+(RCCL all-gather) -> N x N pairwise distance.  Because alpha is O(N^2), every images/sec figure is tied to
+the category size N.  --config selects the BASELINE.json workload:
 
-    python bench.py                      # 1 GPU, default steps
+    2        one category, "bottle"-shaped test set (N = 83), unsupervised tau = 1         [default]
+    2-pill   the largest category ("pill"-shaped, N = 167)
+    3        all 15 MVTec-AD-shaped categories one after another (sum N = 1725), unsupervised;
+             value = 1725 / (time of one pass over all 15); per-category table in `per_category`
+    4        as 3 but supervised, train_ratio 1.0: a bank of M = N_test seeded train images per category
+    5a       one synthetic category of --n images (default 10 000), `average` weights (extract + X + pdist)
+    5b       the same, unsupervised tau = 1: the N x N pair stress.  At N = 10 000 one step is 5.0e17 FLOP
+             (about 10 minutes of MFMA work per GPU on 8 GPUs); `--n 2000` (2.0e16 FLOP, ~25 s on one GPU)
+             runs the same code path (sub-blocked ring schedule) and scales by N(N-1): say so when quoting.
+
+Random-init ViT-B/8 weights of the named architecture (no checkpoint or dataset is reachable offline).  With
+--gpus G the images of every category are sharded over G ranks (strong scaling of the same workload).
+
+    python bench.py                      # 1 GPU, config 2
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel (gemm2::kernel<EpiPairMin, true>, the fused all-pairs
-                 min-distance MFMA GEMM): algorithmic FLOPs per launch / average launch
-                 duration measured with events on the launch stream inside the timed region.
-  cpu_baseline - the CPU oracle (a port of the reference's arithmetic) timed on this host on a
-                 bounded sample of the same workload, N=1 run only.
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline       the dominant kernel (the fused all-pairs min-distance MFMA GEMM, gemm2::kernel<EpiPairMin,true>;
+                 for `average` workloads the ViT forward): algorithmic FLOPs / launch time measured with events
+                 on the launch stream inside the timed region.
+  cpu_baseline   the CPU oracle (a port of the reference's arithmetic) timed on this host, N = 1 run only.
+  h2d_inclusive  the same step with the images starting in pinned host memory (SURVEY 8d's metric starts at
+                 the H2D copy; `value` starts with the images resident, as the bench contract asks).
+  ward_metrics_ms  host Ward linkage + tree cut + Hungarian relabel + NMI/ARI/F1 on the step's distances (outside
+                 the metric, reported separately as SURVEY 8d asks).
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -33,28 +47,34 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP16_MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+VIT_GFLOP_PER_IMAGE = 156.3
+CONFIGS = ("2", "2-pill", "3", "4", "5a", "5b")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--category", default="bottle", help="MVTec-AD category whose test-set shape is used")
+    ap.add_argument("--steps", type=int, default=None, help="default: 3 (configs 2*), 1 otherwise")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 1 (configs 2*, 3, 4), 0 for config 5")
+    ap.add_argument("--config", default="2", choices=CONFIGS)
+    ap.add_argument("--category", default=None, help="config 2 only: another MVTec-AD category shape")
+    ap.add_argument("--n", type=int, default=10000, help="config 5: images in the synthetic category")
     ap.add_argument("--batch", type=int, default=128, help="images per ViT launch")
-    ap.add_argument("--mode", default="unsupervised", choices=["unsupervised", "supervised", "average"])
     ap.add_argument("--tau", type=float, default=1.0)
+    ap.add_argument("--budget-mb", type=int, default=1024, help="memory budget of one matrix of minima")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "slices", "ring"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=32, help="category size of the measured CPU baseline")
+    ap.add_argument("--no-extras", action="store_true", help="skip h2d_inclusive / ward_metrics_ms / stage_ms")
     return ap.parse_args()
 
 
 def pmc_traffic(workload_key, kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary of the SAME workload
     (profiles/*_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes of this
-    script; FETCH_SIZE x2 correction for gfx950).  None when no matching profile is committed."""
+    script; FETCH_SIZE x2 correction for gfx950).  (None, None) when no matching profile is committed."""
     import glob
-    best = None
+    best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(f))
@@ -64,41 +84,129 @@ def pmc_traffic(workload_key, kernel_substr):
             continue
         for k, v in d.items():
             if kernel_substr in k and "hbm_read_bytes_per_launch" in v and "hbm_write_bytes_per_launch" in v:
-                best = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+                best = (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"], os.path.relpath(f, ROOT))
     return best
 
 
-def cpu_baseline(n_sample, n_full, category):
-    """Time the oracle on a bounded sample: n_sample images embedded, all ordered pairs among them
-    for alpha; extrapolate to the category size by per-image and per-pair cost."""
+# ------------------------------------------------------------------ CPU baseline (oracle = port of the reference)
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _cpu_run(sd, images, n):
+    """The reference's arithmetic on n images end to end (batch 1 ViT + aggregation, all ordered alpha pairs,
+    weighted average, pdist): (seconds embed, seconds alpha, seconds tail)."""
     from oracle import vit as ovit, aggregate as oagg, alpha as oalpha, cluster as ocluster
+    t0 = time.perf_counter()
+    Zs = []
+    for i in range(n):                                       # reference runs batch size 1 (main.py:213)
+        taps = ovit.forward_taps(sd, images[i:i + 1], taps=(10, 11))
+        Zs.append(oagg.aggregate([taps[10], taps[11]], 3, 2048, 4096)[0])
+    Z = torch.stack(Zs)
+    t1 = time.perf_counter()
+    a64 = oalpha.matrix_alpha_unsupervised(1.0, 1, Z)
+    t2 = time.perf_counter()
+    _, X = oalpha.weighted_average(a64, Z)
+    ocluster.pdist(X)
+    t3 = time.perf_counter()
+    return t1 - t0, t2 - t1, t3 - t2
+
+
+def cpu_baseline(n_meas, n_quote, category):
+    """Measured: N = n_meas images of the category end to end at the best thread count of a short sweep, and a
+    1-thread run on a smaller sample.  Extrapolated (labelled): the quoted workload size n_quote from the
+    measured per-image and per-pair costs."""
     import patchcore.vision_transformer as vits
     from patchcore.datasets import synthetic
     torch.manual_seed(0)
     model = vits.vit_base(patch_size=8, num_classes=0)
     sd = {k: v.detach() for k, v in model.state_dict().items()}
-    labels = synthetic.category_labels(category)[:n_sample]
+    labels = synthetic.category_labels(category if category in synthetic.TEST_HISTOGRAMS else "bottle")
+    step = max(1, len(labels) // n_meas)
+    labels = labels[::step][:n_meas]                          # spread over the classes
+    n_meas = len(labels)
     images = synthetic.make_images(category, labels)
-    threads = torch.get_num_threads()
-    t0 = time.perf_counter()
-    Zs = []
-    for i in range(n_sample):                                # reference runs batch size 1 (main.py:213)
-        taps = ovit.forward_taps(sd, images[i:i + 1], taps=(10, 11))
-        Zs.append(oagg.aggregate([taps[10], taps[11]], 3, 2048, 4096)[0])
-    Z = torch.stack(Zs)
-    t_embed = (time.perf_counter() - t0) / n_sample
-    t0 = time.perf_counter()
-    a64 = oalpha.matrix_alpha_unsupervised(1.0, 1, Z)
-    t_pair = (time.perf_counter() - t0) / (n_sample * (n_sample - 1))
-    t0 = time.perf_counter()
-    _, X = oalpha.weighted_average(a64, Z)
-    ocluster.pdist(X)
-    t_tail = (time.perf_counter() - t0) / n_sample
-    total = n_full * (t_embed + t_tail) + n_full * (n_full - 1) * t_pair
-    return {"value": n_full / total, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d images embedded (ViT+aggregate, batch 1) + %d ordered alpha pairs on the host; "
-                      "extrapolated to N=%d with %.3f s/image + %.4f s/pair"
-                      % (n_sample, n_sample * (n_sample - 1), n_full, t_embed + t_tail, t_pair)}
+    nproc = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= nproc} | {min(nproc, default_threads)}):
+        torch.set_num_threads(th)
+        e, a, t = _cpu_run(sd, images, 3)                     # probe: 3 images, 6 ordered pairs
+        sweep[th] = e + a + t
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    e, a, t = _cpu_run(sd, images, n_meas)
+    total = e + a + t
+    per_img, per_pair = (e + t) / n_meas, a / max(1, n_meas * (n_meas - 1))
+    torch.set_num_threads(1)
+    n1 = min(n_meas, 5)
+    e1, a1, t1 = _cpu_run(sd, images, n1)
+    torch.set_num_threads(default_threads)
+    quote = n_quote / (n_quote * per_img + n_quote * (n_quote - 1) * per_pair)
+    return {"value": n_meas / total, "unit": "images/sec", "cores": best, "kind": "port",
+            "sample": "MEASURED: N=%d images of the %s-shaped category end to end on the host (ViT+aggregate batch 1, "
+                      "all %d ordered alpha pairs, weighted average, pdist) at %d torch threads = best of the sweep %s "
+                      "(seconds for a 3-image probe)" % (n_meas, category, n_meas * (n_meas - 1), best,
+                                                         {k: round(v, 2) for k, v in sweep.items()}),
+            "n": n_meas, "seconds": total, "s_per_image": per_img, "s_per_pair": per_pair,
+            "one_thread": {"n": n1, "images_per_sec": n1 / (e1 + a1 + t1), "seconds": e1 + a1 + t1},
+            "extrapolated_to_workload": {"n": n_quote, "images_per_sec": quote,
+                                         "rule": "N / (N * s_per_image + N(N-1) * s_per_pair), EXTRAPOLATED"},
+            "nproc": nproc, "cpu_model": _cpu_model(), "torch_default_threads": default_threads}
+
+
+# ------------------------------------------------------------------ workloads
+def build_workload(args, dev):
+    """-> (name, list of dict(category, images (device), train (device or None), labels), mode)."""
+    from patchcore.datasets import synthetic
+    cats = list(synthetic.TEST_HISTOGRAMS)
+    cfg = args.config
+    mode = {"2": "unsupervised", "2-pill": "unsupervised", "3": "unsupervised", "4": "supervised", "5a": "average",
+            "5b": "unsupervised"}[cfg]
+    items = []
+    if cfg in ("2", "2-pill"):
+        cat = args.category or ("pill" if cfg == "2-pill" else "bottle")
+        labels = synthetic.category_labels(cat)
+        items.append({"category": cat, "labels": labels, "images": synthetic.make_images(cat, labels)})
+        name = ("MVTec-AD single category (%s-shaped test set, N=%d), dino_vitbase8 blocks.10+11, 2048->4096, "
+                "patchsize 3, unsupervised alpha tau=%g, random-init weights" % (cat, len(labels), args.tau))
+    elif cfg in ("3", "4"):
+        for cat in cats:
+            labels = synthetic.category_labels(cat)
+            it = {"category": cat, "labels": labels, "images": synthetic.make_images(cat, labels)}
+            if cfg == "4":
+                from patchcore.pipeline import select_bank
+                ntr = synthetic.TRAIN_SIZES[cat]
+                sel = select_bank(ntr, len(labels), 1.0, 0)
+                # only the M = N_test selected bank images are ever embedded (main.py:281)
+                tr = synthetic.make_images(cat, ["good"] * ntr, split=synthetic.DatasetSplit.TRAIN)
+                it["train"] = tr[sel].contiguous()            # M = N_test images: run_category's own selection then keeps all
+            items.append(it)
+        name = ("MVTec-AD all 15 categories (test-set sizes 83..167, sum N=%d), dino_vitbase8 blocks.10+11, 2048->4096, "
+                "patchsize 3, %s%s, random-init weights, categories one after another"
+                % (sum(len(i["labels"]) for i in items), mode,
+                   " alpha tau=%g" % args.tau if cfg == "3" else " alpha (bank M=N_test per category, train_ratio 1.0)"))
+    else:
+        n = args.n
+        # class labels so that clustering has an answer: 5 classes in equal blocks
+        kinds = ["good", "a", "b", "c", "d"]
+        labels = [kinds[(i * len(kinds)) // n] for i in range(n)]
+        items.append({"category": "synthetic%d" % n, "labels": labels,
+                      "images": synthetic.make_images("synthetic", labels)})
+        name = ("synthetic category of N=%d images, dino_vitbase8 blocks.10+11, patchsize 3, 2048->4096, %s%s, "
+                "random-init weights" % (n, mode, " alpha tau=%g" % args.tau if mode == "unsupervised" else " weights"))
+    for it in items:
+        it["images_host"] = it["images"].pin_memory() if torch.cuda.is_available() else it["images"]
+        it["images"] = it["images"].to(dev)
+        if it.get("train") is not None:
+            it["train"] = it["train"].to(dev)
+    return name, items, mode
 
 
 def main():
@@ -113,8 +221,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL smoke before anything is timed: communicator creation + a 1-element all-reduce
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise SystemExit("RCCL all-reduce smoke failed: %r" % probe.item())
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    steps = args.steps if args.steps is not None else (3 if args.config.startswith("2") else 1)
+    warmup = args.warmup if args.warmup is not None else (0 if args.config.startswith("5") else 1)
 
     import acnative
     import patchcore.backbones
@@ -122,7 +238,6 @@ def main():
     import patchcore.sampler
     from patchcore.patchcore import AnomalyClusteringCore
     from patchcore.pipeline import HipOps, run_category
-    from patchcore.datasets import synthetic
 
     os.environ.setdefault("AC_BACKBONE_SEED", "0")       # random-init weights of the named architecture (no checkpoint offline)
     backbone = patchcore.backbones.load("dino_vitbase8")
@@ -132,77 +247,127 @@ def main():
               featuresampler=patchcore.sampler.IdentitySampler(), anomaly_scorer_num_nn=5,
               nn_method=common.FaissNN(True, 4))
     ops = HipOps(core, batch_size=args.batch)
-    labels = synthetic.category_labels(args.category)
-    n = len(labels)
-    images = synthetic.make_images(args.category, labels).to(dev)      # resident in HBM before timing
-    train = None
-    if args.mode == "supervised":
-        train = synthetic.make_images(args.category, synthetic.category_labels(args.category, synthetic.DatasetSplit.TRAIN),
-                                      split=synthetic.DatasetSplit.TRAIN).to(dev)
+    name, items, mode = build_workload(args, dev)            # images resident in HBM before timing
+    n_total = sum(len(it["labels"]) for it in items)
+    budget = args.budget_mb << 20
 
-    def step(timings=None):
-        return run_category(ops, images, args.mode, tau=args.tau, train_images=train, want_host=False,
-                            timings=timings)
+    def run_item(it, images, timings=None):
+        return run_category(ops, images, mode, tau=args.tau, train_images=it.get("train"), train_ratio=1.0,
+                            want_host=False, timings=timings, budget=budget, schedule=args.schedule)
+
+    def step(timings=None, from_host=False, per_cat=None):
+        outs = []
+        for it in items:
+            t0 = time.perf_counter()
+            images = it["images_host"].to(dev, non_blocking=True) if from_host else it["images"]
+            outs.append(run_item(it, images, timings))
+            if per_cat is not None:
+                torch.cuda.synchronize()
+                per_cat.append(time.perf_counter() - t0)
+        return outs
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def timed(k, **kw):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = step(**kw)
+        fence()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return el.item(), out
+
+    for _ in range(warmup):
         step()
-    fence()
-    acnative.kernel_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    acnative.kernel_events = [] if mode != "average" else None
+    vit_events = []
+    if mode == "average":                                      # dominant = the ViT forward: events around the embed stage
+        orig_embed = ops.embed
+
+        def embed_timed(images):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            z = orig_embed(images)
+            e1.record()
+            vit_events.append((e0, e1, images.shape[0]))
+            return z
+        ops.embed = embed_timed
+    elapsed, last = timed(steps)
     events, acnative.kernel_events = acnative.kernel_events, None
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = tmax.item()
+    if mode == "average":
+        ops.embed = orig_embed
 
     # roofline of the dominant kernel from the events recorded inside the timed region
     roof = None
+    key = "%s:%s:%d:gpus%d" % (items[0]["category"] if len(items) == 1 else "all15", mode, n_total, world)
     if events:
         ms = [e0.elapsed_time(e1) for (_, e0, e1, *_s) in events]
-        flops = [2.0 * (nk * P) * (qn * P) * D for (_, _, _, nk, qn, P, D) in events]
-        avg_ms = sum(ms) / len(ms)
-        avg_flop = sum(flops) / len(flops)
-        ach = avg_flop / (avg_ms * 1e-3) / 1e12
+        flops = [pairs * 2.0 * P * P * D for (_, _, _, pairs, P, D) in events]
+        ach = sum(flops) / (sum(ms) * 1e-3) / 1e12
+        traffic, src = pmc_traffic(key, "EpiPairMin")
         roof = {"bound": "mfma", "kernel": "gemm2::kernel<EpiPairMin, true>", "achieved": ach,
                 "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP16_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic("%s:%s:%d:gpus%d" % (args.category, args.mode, n, world), "EpiPairMin"),
-                "avg_launch_ms": avg_ms, "launches": len(ms),
-                "note": "achieved = algorithmic 2*P^2*D FLOP per ORDERED image pair / launch time. The kernel issues 3 "
-                        "fp16 MFMA passes per product (split-fp16, fp32-grade) and, when keys == queries, computes "
-                        "only the upper triangle of tiles (each reduced both ways), so issued MFMA work = 1.5x the "
-                        "algorithmic FLOPs on one GPU and frac <= 2/3 by construction; traffic = L2-miss (fabric) "
-                        "bytes per launch from the committed PMC passes of this workload"}
+                "traffic": traffic, "traffic_source": src,
+                "avg_launch_ms": sum(ms) / len(ms), "launches": len(ms), "launches_per_step": len(ms) / steps,
+                "algorithmic_flop_per_launch": sum(flops) / len(flops),
+                "note": "achieved = algorithmic 2*P^2*D FLOP per ORDERED image pair (N(N-1) pairs per category; a bank "
+                        "of M images: N*M) / launch time. The kernel issues 3 fp16 MFMA passes per product (split-fp16, "
+                        "fp32-grade) and reduces every symmetric / two-way block in both directions from one pass, so "
+                        "issued MFMA work = 1.5x the algorithmic FLOPs (3x for the one-way supervised blocks) and frac <= "
+                        "2/3 (1/3) by construction; traffic = L2-miss (fabric) bytes per launch from the committed PMC "
+                        "passes named in traffic_source (rank 0's launches)"}
+    elif vit_events:
+        ms = [e0.elapsed_time(e1) for (e0, e1, _) in vit_events]
+        imgs = sum(n for (_, _, n) in vit_events)
+        ach = imgs * VIT_GFLOP_PER_IMAGE * 1e9 / (sum(ms) * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "ViT forward + aggregation (embed stage: gemm5::kernel<...>, attention_kernel)",
+                "achieved": ach, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP16_MFMA_PEAK_TFLOPS,
+                "traffic": None, "note": "156.3 GFLOP per image (SURVEY 8a) / embed time; split-fp16: frac <= 1/3"}
 
-    # per-stage breakdown (one extra, untimed-for-the-metric step)
-    stages = {}
-    step(timings=stages)
-
+    out = {
+        "metric": "images/sec end-to-end (extract+alpha+pairwise)",
+        "value": n_total * steps / elapsed, "unit": "images/sec", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32 (split-fp16 MFMA, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": name, "baseline_config": args.config, "images_per_step": n_total,
+                   "categories": len(items), "vit_batch": args.batch, "alpha_schedule": args.schedule,
+                   "minbuf_budget_mb": args.budget_mb,
+                   "parallelism": "images of each category sharded over %d rank(s); RCCL all-gather of packed "
+                                  "shards / ring of shards, all-gather of X and alpha" % world},
+        "roofline": roof,
+    }
+    if not args.no_extras:
+        per_cat, stages = [], {}
+        step(timings=stages, per_cat=per_cat)                   # one extra, untimed-for-the-metric step
+        out["stage_ms"] = {k: 1e3 * v for k, v in stages.items()}
+        if len(items) > 1:
+            out["per_category"] = [{"category": it["category"], "n": len(it["labels"]), "ms": 1e3 * t,
+                                    "images_per_sec": len(it["labels"]) / t} for it, t in zip(items, per_cat)]
+        if args.config.startswith("2") or args.config in ("3", "4"):
+            el, _ = timed(1, from_host=True)
+            out["h2d_inclusive"] = {"value": n_total / el, "ms_per_step": 1e3 * el,
+                                    "note": "same step, images start in pinned host memory (0.60 MB/image over PCIe)"}
+        if rank == 0:
+            from patchcore.clustering import cluster_metrics_from_pdist
+            t0 = time.perf_counter()
+            res = []
+            for it, o in zip(items, last):
+                if "pdist" in o:
+                    res.append(cluster_metrics_from_pdist(o["pdist"], it["labels"]))
+            out["ward_metrics_ms"] = 1e3 * (time.perf_counter() - t0)
+            out["clustering"] = {"NMI": sum(r[0] for r in res) / len(res), "ARI": sum(r[1] for r in res) / len(res),
+                                 "F1": sum(r[2] for r in res) / len(res),
+                                 "note": "mean over the step's categories, synthetic labels (not part of the metric)"}
     if rank == 0:
-        out = {
-            "metric": "images/sec end-to-end (extract+alpha+pairwise)",
-            "value": n * args.steps / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (split-fp16 MFMA, fp32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": "MVTec-AD single category (%s-shaped test set, N=%d), dino_vitbase8 "
-                                   "blocks.10+11, 2048->4096, patchsize 3, %s alpha tau=%g, random-init weights"
-                                   % (args.category, n, args.mode, args.tau),
-                       "images_per_category": n, "vit_batch": args.batch,
-                       "parallelism": "images sharded over %d rank(s), RCCL all-gather of Z and X" % world},
-            "stage_ms": {k: 1e3 * v for k, v in stages.items()},
-            "roofline": roof,
-        }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, n, args.category)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, len(items[0]["labels"]) if len(items) == 1 else 115,
+                                               items[0]["category"] if items[0]["category"] in ("bottle", "pill") else "bottle")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

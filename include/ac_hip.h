@@ -66,6 +66,18 @@ int ac_set_gemm_policy(int policy);
 int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_ld, void* dst_hl32,
                  float* row_sqnorm, void* stream);
 
+/* ------------------------------------------------------------- input pipeline */
+
+/* The image transform of the MVTec dataset (models/patchcore/datasets/mvtec.py:74-81), batched:
+ *   Resize(resize) (short edge, Pillow's antialiased bilinear, uint8 after each pass) -> CenterCrop(crop) ->
+ *   ToTensor (/255) -> Normalize(mean, std)
+ * images: DEVICE uint8 [B, H, W, 3] (decoded RGB, all of one size); mean, std: HOST float[3];
+ * out: fp32 [B, 3, crop, crop] (NCHW), what ac_vit_prepare_tokens reads.  Bit-identical to the host chain
+ * (integer resampling; fp32 division / subtraction / division, IEEE-rounded). */
+size_t ac_preprocess_workspace_bytes(int B, int H, int W, int resize, int crop);
+int ac_preprocess_images(const uint8_t* images, int B, int H, int W, int resize, int crop, const float* mean,
+                         const float* stddev, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ----------------------------------------------------------------------- ViT */
 
 /* Weights of one transformer block, reference models/patchcore/vision_transformer.py:95-113.
@@ -145,23 +157,48 @@ size_t ac_pair_min_dist_workspace_bytes(int64_t nq, int64_t nk, int P, int D);
 int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, int P, int D, int reduce,
                      int64_t self_offset, float* w, void* ws, size_t ws_bytes, void* stream);
 
-/* The same computation in stages, for callers that keep packed operands resident (multi-GPU
- * shards, tau sweeps) or time the MFMA kernel alone:
+/* The same computation in stages, for callers that keep packed operands resident, split a category into
+ * blocks that fit a memory budget, shard it over GPUs (models/patchcore/pipeline.py), or time the MFMA
+ * kernel alone.  The reference's per-pair loop being replaced is utils.py:222-237.
+ *
  *   ac_pack_hl32(Z, rows = n*P, K = D, ..., row_sqnorm)            -> Z_hl, sq
- *   ac_pair_min_sq_packed: minbuf[j][i*P + p] = min(minbuf, min_q d2(Zq[i][p], Zk[j][q])) as the
- *       IEEE bits of a non-negative float; the caller presets minbuf (uint32 [nk][nq*P]) to +inf
- *       (0x7f800000).  This call launches exactly one kernel (the MFMA GEMM with the fused min).
- *       When Zq and Zk are the same packed buffer (nq == nk) the problem is symmetric and only the
- *       upper triangle of tiles is computed, each reduced in both directions.
- *       part / nparts (0 / 1 = everything): compute only the part-th of nparts equal slices of the
- *       tile grid - several GPUs each take a slice of one symmetric problem into their own minbuf and
- *       combine with an element-wise MIN all-reduce.
- *   ac_pair_reduce: w[i][p] = mean_{j != self_first + i} sqrt(minbuf[j][..]) or sqrt(min_j ..). */
+ *
+ *   ac_pair_min_sq_packed: ONE launch of the MFMA GEMM with the fused min, on the rectangle
+ *       keys (nk images) x queries (nq images):
+ *         minbuf[j][i*P + p]   = min(minbuf[..],   min_q d2(Zq[i][p], Zk[j][q]))     uint32 [nk][nq*P]
+ *         minbuf_t[i][j*P + q] = min(minbuf_t[..], min_p d2(Zq[i][p], Zk[j][q]))     uint32 [nq][nk*P]
+ *       as the IEEE bits of a non-negative float; the caller presets them to +inf (0x7f800000).
+ *       - minbuf_t == NULL: one direction only (supervised: test patches against the normal bank).
+ *       - minbuf_t != NULL ("two-way"): the block between two DIFFERENT image sets of one unsupervised
+ *         category is reduced in both directions from a single pass over its tiles, so a category costs
+ *         N^2/2 image pairs of MFMA work however it is blocked.
+ *       - Zq and Zk the same packed buffer (nq == nk, minbuf_t NULL): the symmetric case; only the upper
+ *         triangle of tiles runs, each reduced both ways into minbuf.  part / nparts (0 / 1 = everything):
+ *         only the part-th of nparts equal slices of that tile grid - several GPUs each take a slice of one
+ *         small symmetric problem into their own minbuf and combine with an element-wise MIN all-reduce.
+ *
+ *   ac_max_f32 / ac_pair_fixed_shift: the fixed-point scale of the unsupervised sum.  The mean over key
+ *       images is accumulated as 64-bit integers (each sqrt scaled by 2^shift and rounded) so that the
+ *       result does not depend on how the key images are blocked, ordered or spread over ranks.
+ *       max_sq (device, preset to 0): running max of the squared norms of every row of the category
+ *       (all-reduce MAX across ranks); shift (device int32) = min(40, 62 - ceil(log2(n_keys*2*sqrt(max_sq)))).
+ *
+ *   ac_pair_accumulate: fold a minbuf block (nk rows of stride ld, ncols query columns) into acc:
+ *       MEAN_OTHERS: acc int64 [ncols] += sum_{j != self_first + col/P} round(sqrt(minbuf[j][col]) * 2^shift)
+ *                    (self_first = index, within this block's key rows, of the key image that IS the first
+ *                    query image; any value outside [-(ncols/P), nk) skips nothing);  preset acc to 0.
+ *       MIN_ALL:     acc uint32 [ncols] = min(acc, min_j minbuf[j][col]);               preset acc to +inf bits.
+ *   ac_pair_finalize: w = (float)(acc * 2^-shift / count)  or  sqrt(acc as float).  count = number of key
+ *       images that entered the mean (N - 1). */
 int ac_pair_min_sq_packed(const void* Zk_hl32, const float* k_sqnorm, int64_t nk, const void* Zq_hl32,
-                          const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, int part,
-                          int nparts, void* stream);
-int ac_pair_reduce(const uint32_t* minbuf, int64_t nk, int64_t nq, int P, int reduce, int64_t self_first,
-                   float* w, void* stream);
+                          const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, uint32_t* minbuf_t,
+                          int part, int nparts, void* stream);
+int ac_max_f32(const float* x, int64_t n, float* max_out, void* stream);
+int ac_pair_fixed_shift(const float* max_sq, int64_t n_keys, int32_t* shift, void* stream);
+int ac_pair_accumulate(const uint32_t* minbuf, int64_t nk, int64_t ld, int64_t ncols, int P, int reduce,
+                       int64_t self_first, const int32_t* shift, void* acc, void* stream);
+int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift, float* w,
+                     void* stream);
 
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
  *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;

@@ -21,8 +21,11 @@ Pinning status (see DESIGN.md "Oracle"):
     ``tests/golden/make_golden.py`` (which is committed next to the vectors
     it wrote).
 
+  * image transform (Resize / CenterCrop / ToTensor / Normalize) - torchvision is absent; pinned one level
+    down, against Pillow itself (the arithmetic torchvision runs for PIL inputs) and a committed fixture.
+
 Every function cites the reference file:line it restates; paths are relative
 to ``/root/reference/Anomaly-Clustering/``.
 """
 
-from . import vit, aggregate, alpha, cluster  # noqa: F401
+from . import vit, aggregate, alpha, cluster, preprocess  # noqa: F401

@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/Anomaly-Clustering"
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from _synth import hash_tensor, gaussish_tensor, clustered_embeddings  # noqa: E402
+from _synth import hash_tensor, gaussish_tensor, clustered_embeddings, dino_like_statistics  # noqa: E402
 
 
 def import_reference():
@@ -54,13 +54,62 @@ PATCH_ROWS = [0, 1, 27, 28, 29, 55, 391, 392, 406, 419, 420, 756, 757, 782, 783]
 TOKENS = [0, 1, 2, 28, 29, 392, 783, 784]
 
 
-def main(only_kat=False):
+def a15_fixture():
+    """A small RGB image (RNG-free content: smooth gradients + blocks + hash noise) saved as PNG, and what the
+    reference's transform chain returns for it.  torchvision is absent here; for PIL inputs its Resize(256) /
+    CenterCrop(224) are Pillow's Image.resize(BILINEAR) / crop (sizes and offsets as in torchvision's
+    functional.py), ToTensor / Normalize are torch ops - the chain below IS those calls."""
+    import PIL.Image
+    h, w = 300, 340
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 100 * np.sin(xx / 23.0) * np.cos(yy / 31.0), (xx * 255.0 / w), ((xx // 40 + yy // 25) % 2) * 180.0 + 30], -1)
+    noise = hash_tensor((h, w, 3), salt=77, scale=40.0, dtype=np.float64)
+    img = np.clip(base + noise, 0, 255).astype(np.uint8)
+    PIL.Image.fromarray(img).save(os.path.join(HERE, "a15_image.png"), optimize=True)
+    pil = PIL.Image.open(os.path.join(HERE, "a15_image.png")).convert("RGB")
+    nw, nh = (256, int(256 * h / w)) if w <= h else (int(256 * w / h), 256)
+    r = pil.resize((nw, nh), PIL.Image.BILINEAR)
+    top, left = int(round((nh - 224) / 2.0)), int(round((nw - 224) / 2.0))
+    r = r.crop((left, top, left + 224, top + 224))
+    u8 = np.asarray(r)
+    t = torch.from_numpy(np.ascontiguousarray(u8)).permute(2, 0, 1).to(torch.float32).div(255)
+    t = (t - torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    np.savez_compressed(os.path.join(HERE, "a15_expected.npz"), shape=np.array(img.shape),
+                        cropped_u8=np.transpose(u8, (2, 0, 1)), check=checksums(t))
+    print("a15 fixture", img.shape, (nh, nw), (top, left), checksums(t))
+
+
+def main(only_kat=False, only_dino=False):
     torch.set_num_threads(8)
     vits, common, pc, utils, sampler = import_reference()
     dev = torch.device("cpu")
+    if only_dino:
+        return dino_stats_golden(vits, common, dev)
     if not only_kat:
         compute_goldens(vits, common, pc, utils, sampler, dev)
     known_answer_rows()
+
+
+def dino_stats_golden(vits, common, dev):
+    """Only G1b (see compute_goldens): written separately so that the other fixtures need not be regenerated."""
+    images = torch.from_numpy(gaussish_tensor((2, 3, 224, 224), salt=11, scale=1.7))
+    torch.manual_seed(0)
+    model_d = vits.vit_base(patch_size=8, num_classes=0)
+    for p in model_d.parameters():
+        p.requires_grad = False
+    model_d.eval()
+    sd_d = model_d.state_dict()
+    dino_like_statistics(sd_d)
+    agg_d = common.NetworkFeatureAggregator(model_d, ["blocks.10", "blocks.11"], dev)
+    feats_d = agg_d(images)
+    d10, d11 = feats_d["blocks.10"].clone(), feats_d["blocks.11"].clone()
+    names_d = sorted(sd_d.keys())
+    np.savez(os.path.join(HERE, "vit_forward_dino_stats.npz"),
+             tokens=np.array(TOKENS), f10=d10[:, TOKENS].numpy(), f11=d11[:, TOKENS].numpy(),
+             f10_check=checksums(d10), f11_check=checksums(d11),
+             weight_checks=np.stack([checksums(sd_d[k]) for k in names_d]),
+             absmax=np.array([d10.abs().max().item(), d11.abs().max().item()]))
+    print("G1b done", checksums(d10), checksums(d11), d10.abs().max().item(), d11.abs().max().item())
 
 
 def compute_goldens(vits, common, pc, utils, sampler, dev):
@@ -86,6 +135,10 @@ def compute_goldens(vits, common, pc, utils, sampler, dev):
              tokens=np.array(TOKENS), f10=f10[:, TOKENS].numpy(), f11=f11[:, TOKENS].numpy(),
              f10_check=checksums(f10), f11_check=checksums(f11), feature_dimensions=np.array(fdims))
     print("G1 done", checksums(f10), checksums(f11))
+
+    # ---------------- G1b: the same network with DINO-like statistics ------------
+    dino_stats_golden(vits, common, dev)
+    agg = common.NetworkFeatureAggregator(model, ["blocks.10", "blocks.11"], dev)     # hooks back on the plain model
 
     # ---------------- G2: aggregation through the reference's _embed -------------
     core = pc.AnomalyClusteringCore(dev)
@@ -232,4 +285,7 @@ def known_answer_rows():
 
 
 if __name__ == "__main__":
-    main(only_kat="--kat" in sys.argv)
+    if "--a15" in sys.argv:
+        a15_fixture()
+    else:
+        main(only_kat="--kat" in sys.argv, only_dino="--dino" in sys.argv)

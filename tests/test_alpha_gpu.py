@@ -151,10 +151,85 @@ def test_partitioned_symmetric_slices_combine_to_the_whole(dev):
         combined = torch.stack(parts).min(0)[0]
         assert torch.equal(combined, whole), G
         assert sum(int(torch.isfinite(p).sum()) for p in parts) >= whole.numel()     # slices cover everything
-    w = acnative.pair_reduce(whole, 784, acnative.REDUCE_MEAN_OTHERS, 0)
+    msq = acnative.max_sq([acnative.pack_images(Z)], dev)          # the category's fixed-point scale
+    w = acnative.pair_reduce(whole, 784, acnative.REDUCE_MEAN_OTHERS, 0, max_sq_t=msq)
     assert torch.equal(w, acnative.pair_min_dist_staged(Z, Z, acnative.REDUCE_MEAN_OTHERS))
-    w_part = acnative.pair_reduce(whole[:, 784:3 * 784].contiguous(), 784, acnative.REDUCE_MEAN_OTHERS, 1)
+    assert torch.equal(w, acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS))
+    w_part = acnative.pair_reduce(whole[:, 784:3 * 784], 784, acnative.REDUCE_MEAN_OTHERS, 1, max_sq_t=msq, n_keys=5)
     assert torch.equal(w_part, w[1:3])
+
+
+def test_two_way_block_against_one_way_blocks(dev):
+    """The two-way launch (a rectangle between two different image sets, every tile reduced in both
+    directions): the forward matrix is exactly what a one-way launch fills; the transposed matrix holds the
+    same distances as the one-way launch with the operands exchanged, up to the last bits (a.b and b.a
+    accumulate their three split-fp16 passes in a different order) - ragged shapes: P not a multiple of the
+    tile, nk != nq, blocks of one image."""
+    import acnative
+    for (na, nb, P, D, salt) in [(3, 2, 100, 256, 57), (1, 4, 67, 96, 58), (2, 2, 784, 128, 59), (5, 1, 130, 64, 60)]:
+        Zs, _ = clustered_embeddings(na + nb, P, D, 3, salt=salt)
+        pk = acnative.pack_images(torch.from_numpy(Zs).to(dev))
+        A, B = pk.slice(0, na), pk.slice(na, na + nb)
+        mb, mbt = acnative.pair_block(A, B, two_way=True)
+        assert torch.equal(mb, acnative.pair_block(A, B)), (na, nb, P, D)
+        other = acnative.pair_block(B, A).view(torch.float32)
+        assert (mb != acnative.INF_BITS).all() and (mbt != acnative.INF_BITS).all()
+        np.testing.assert_allclose(mbt.view(torch.float32).cpu().numpy(), other.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="symmetric case"):
+        acnative.pair_block(A, A, two_way=True)
+
+
+class _IdentityOps:
+    """HipOps whose 'images' ARE the embeddings Z [N, P, D]: isolates the alpha engine from the ViT."""
+
+    def __new__(cls):
+        from patchcore.pipeline import HipOps
+        ops = HipOps(core=None)
+        ops.embed = lambda images: images.contiguous()
+        return ops
+
+
+def test_block_schedules_are_bit_identical_on_one_gpu(dev):
+    """run_category's unsupervised engine on one GPU: one symmetric launch (default budget) vs the ring
+    schedule forced into sub-blocks of 1, 2 and 3 images (symmetric diagonal blocks + two-way off-diagonal
+    blocks + the fixed-point sum): the same bits.  Supervised: sub-blocked one-way blocks == one launch."""
+    from patchcore.pipeline import run_category
+    from oracle import alpha as oa
+    import acnative
+    Zs, _ = clustered_embeddings(7, 100, 256, 3, salt=51)
+    Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=52)
+    Z, Zbank = torch.from_numpy(Zs).to(dev), torch.from_numpy(Zb).to(dev)
+    ops = _IdentityOps()
+    ref = run_category(ops, Z, "unsupervised", tau=1.0)
+    assert torch.equal(ref["w_loc"], acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS))
+    assert _w_close(ref["w_loc"].cpu().numpy(), oa.weights_unsupervised(torch.from_numpy(Zs)).numpy())
+    for c in (1, 2, 3):
+        got = run_category(ops, Z, "unsupervised", tau=1.0, budget=c * c * 100 * 4)
+        assert torch.equal(got["w_loc"], ref["w_loc"]), c
+        assert torch.equal(got["alpha"], ref["alpha"]) and np.array_equal(got["X"], ref["X"])
+    sup = run_category(ops, Z, "supervised", tau=1.0, train_images=Zbank, train_ratio=1.0)
+    sup_small = run_category(ops, Z, "supervised", tau=1.0, train_images=Zbank, train_ratio=1.0, budget=2 * 2 * 100 * 4)
+    assert torch.equal(sup["w_loc"], sup_small["w_loc"])
+    assert _w_close(sup["w_loc"].cpu().numpy(),
+                    oa.weights_supervised(torch.from_numpy(Zs), torch.from_numpy(Zb)).numpy())
+
+
+def test_fixed_point_scale_follows_the_data(dev):
+    """The shift of the 64-bit fixed-point sum comes from n_keys * 2 sqrt(max |z|^2): capped at 40 for ordinary
+    data, lower when many keys or large norms would overflow 2^62 - and w barely notices (resolution 2^-shift)."""
+    import acnative
+    Zs, _ = clustered_embeddings(4, 50, 64, 2, salt=93)
+    big = (Zs * 2.0e3).astype(np.float32)                  # |z| ~ 2e3: inside fp16 range (hl32 needs |z| < 65504)
+    Z = torch.from_numpy(big).to(dev)
+    msq = acnative.max_sq([acnative.pack_images(Z)], dev)
+    assert int(acnative.fixed_shift(msq, 4).item()) == 40
+    assert int(acnative.fixed_shift(msq, 10 ** 9).item()) < 20
+    w = acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS)
+    np.testing.assert_allclose(w.cpu().numpy(), _truth_w(big, big, 0), rtol=2e-6)
+    minbuf = acnative.pair_min_sq_part(Z)
+    assert torch.equal(acnative.pair_reduce(minbuf, 50, acnative.REDUCE_MEAN_OTHERS, 0, max_sq_t=msq), w)
+    coarse = acnative.pair_reduce(minbuf, 50, acnative.REDUCE_MEAN_OTHERS, 0, max_sq_t=msq, n_keys=10 ** 9)
+    np.testing.assert_allclose(coarse.cpu().numpy(), w.cpu().numpy(), rtol=1e-6)
 
 
 def test_query_chunking_with_a_small_minbuf_budget(dev):

@@ -16,8 +16,26 @@ import torch.multiprocessing as mp
 from conftest import ROOT, MODELS
 
 
+INF_BITS = 0x7f800000
+
+
+class ToyPacked:
+    """CPU stand-in for acnative.Packed: the 'packed' image is Z itself, rows image-major."""
+
+    def __init__(self, hl, sq, n, P, D):
+        self.hl, self.sq, self.n, self.P, self.D = hl, sq, n, P, D
+
+    def slice(self, lo, hi):
+        P = self.P
+        return ToyPacked(self.hl[lo * P: hi * P], self.sq[lo * P: hi * P], hi - lo, P, self.D)
+
+    def tensors(self):
+        return [self.hl, self.sq]
+
+
 class ToyOps:
-    """CPU stand-in for HipOps (tests only): tiny embedding + the oracle's alpha arithmetic."""
+    """CPU stand-in for HipOps (tests only): tiny embedding + the oracle's alpha arithmetic behind the same
+    block primitives (pack / pair_block / pair_accumulate in 64-bit fixed point / pair_finalize)."""
     P, D = 12, 32
 
     def embed(self, images):
@@ -27,33 +45,66 @@ class ToyOps:
         flat = images.reshape(n, -1)[:, : self.P * self.D].reshape(n, self.P, self.D)
         return (flat * 1.5 + flat.roll(1, dims=2) * 0.5).contiguous()
 
-    def pair_min_dist(self, Zq, Zk, reduce, self_offset):
-        out = []
-        for i in range(Zq.shape[0]):
-            cols = [(torch.cdist(Zq[i], Zk[j]).min(1)[0] ** 2).sqrt() for j in range(Zk.shape[0])
-                    if not (reduce == 0 and j == i + self_offset)]
-            cols = torch.stack(cols, 1)
-            out.append(cols.mean(1) if reduce == 0 else cols.min(1)[0])
-        return torch.stack(out) if out else torch.zeros(0, Zq.shape[1])
+    def pack(self, Z):
+        n, P, D = Z.shape
+        flat = Z.reshape(n * P, D).contiguous()
+        return ToyPacked(flat, (flat.double() ** 2).sum(1).float(), n, P, D)
 
-    def pair_min_sq_part(self, Z, part, nparts):
-        """Slice = the key images j with j % nparts == part (any disjoint cover works for the MIN all-reduce)."""
-        n, P, _ = Z.shape
-        out = torch.full((n, n * P), float("inf"))
-        for j in range(part, n, nparts):
-            for i in range(n):
-                out[j, i * P:(i + 1) * P] = torch.cdist(Z[i], Z[j]).min(1)[0] ** 2
-        return out
+    def empty_packed(self, n, like):
+        return ToyPacked(torch.empty(n * like.P, like.D), torch.empty(n * like.P), n, like.P, like.D)
 
-    def pair_reduce(self, minbuf, P, reduce, self_first):
-        nk, cols = minbuf.shape
-        d = minbuf.sqrt().reshape(nk, cols // P, P)
-        out = []
-        for i in range(cols // P):
-            rows = [d[j, i] for j in range(nk) if not (reduce == 0 and j == i + self_first)]
-            rows = torch.stack(rows, 1)
-            out.append(rows.mean(1) if reduce == 0 else rows.min(1)[0])
-        return torch.stack(out)
+    def max_sq(self, packed_list, device):
+        m = torch.zeros(1)
+        for pk in packed_list:
+            if pk.n:
+                m = torch.maximum(m, pk.sq.max().reshape(1))
+        return m
+
+    def fixed_shift(self, max_sq_t, n_keys):
+        bound = max(int(n_keys), 1) * 2.0 * float(max_sq_t.double().sqrt()) + 1.0
+        e = np.frexp(bound)[1]
+        return torch.tensor([max(-60, min(40, 62 - int(e)))], dtype=torch.int32)
+
+    def new_acc(self, ncols, reduce, device):
+        if reduce == 0:
+            return torch.zeros(ncols, dtype=torch.int64)
+        return torch.full((ncols,), INF_BITS, dtype=torch.int32)
+
+    def pair_block(self, keys, queries, two_way=False, part=0, nparts=1):
+        P = keys.P
+        same = keys.hl.data_ptr() == queries.hl.data_ptr() and keys.n == queries.n
+        Zk, Zq = keys.hl.reshape(keys.n, P, -1), queries.hl.reshape(queries.n, P, -1)
+        mb = torch.full((keys.n, queries.n * P), float("inf"))
+        mbt = torch.full((queries.n, keys.n * P), float("inf")) if two_way else None
+        for j in range(keys.n):
+            if same and j % nparts != part:            # any disjoint cover works for the MIN all-reduce
+                continue
+            for i in range(queries.n):
+                d2 = torch.cdist(Zq[i], Zk[j]) ** 2          # [P queries, P keys]
+                mb[j, i * P:(i + 1) * P] = d2.min(1)[0]
+                if two_way:
+                    mbt[i, j * P:(j + 1) * P] = d2.min(0)[0]
+        mb = mb.view(torch.int32)
+        return (mb, mbt.view(torch.int32)) if two_way else mb
+
+    def pair_accumulate(self, minbuf, P, reduce, self_first, shift, acc):
+        nk, ncols = minbuf.shape
+        if nk == 0 or ncols == 0:
+            return
+        if reduce == 0:
+            v = torch.round(minbuf.view(torch.float32).sqrt().double() * (2.0 ** int(shift))).to(torch.int64)
+            j = torch.arange(nk).reshape(nk, 1)
+            self_of_col = (self_first + torch.arange(ncols) // P).reshape(1, ncols)
+            acc += torch.where(j == self_of_col, torch.zeros_like(v), v).sum(0)
+        else:
+            torch.minimum(acc, minbuf.min(0)[0], out=acc)
+
+    def pair_finalize(self, acc, P, reduce, count, shift):
+        if reduce == 0:
+            w = (acc.double() * (2.0 ** -int(shift)) / count).float() if count else torch.full(acc.shape, float("nan"))
+        else:
+            w = acc.view(torch.float32).sqrt()
+        return w.reshape(-1, P)
 
     def alpha_softmax(self, w, tau, k):
         from oracle import alpha as oa
@@ -77,12 +128,13 @@ def _inputs(n=7, n_train=9):
     return torch.randn(n, 3, 16, 16, generator=g), torch.randn(n_train, 3, 16, 16, generator=g)
 
 
-def _worker(rank, world, init_file, mode, out_dir):
+def _worker(rank, world, init_file, mode, out_dir, schedule="auto", budget=1 << 30):
     sys.path[:0] = [ROOT, MODELS]
     from patchcore.pipeline import run_category
     dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
     images, train = _inputs()
-    out = run_category(ToyOps(), images, mode, tau=1.0, train_images=train, train_ratio=1.0)
+    out = run_category(ToyOps(), images, mode, tau=1.0, train_images=train, train_ratio=1.0, schedule=schedule,
+                       budget=budget)
     np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].numpy())
     np.save(os.path.join(out_dir, "X_%d.npy" % rank), out["X"])
     if rank == 0:
@@ -105,6 +157,39 @@ def test_two_ranks_equal_one_rank(mode):
         np.testing.assert_array_equal(np.load(os.path.join(d, "pdist.npy")), ref["pdist"].numpy())
     assert ref["alpha"].shape == (7, 1, ToyOps.P) and ref["X"].shape == (7, ToyOps.D)
     np.testing.assert_allclose(ref["alpha"].sum(-1).numpy(), 1.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("world,schedule,budget", [(2, "ring", 1 << 30), (2, "ring", 2 * 2 * 12 * 4), (3, "ring", 12 * 4),
+                                                   (3, "slices", 1 << 30), (4, "ring", 3 * 3 * 12 * 4)])
+def test_unsupervised_schedules_are_bit_identical(world, schedule, budget):
+    """The ring schedule (whole shards, or forced down to 1-3 image sub-blocks by a tiny budget so that the
+    step-G/2 split, the two-way blocks and the int64 all-reduce all engage) and the slices schedule give the
+    SAME BITS as one rank with one block: the fixed-point sum makes the order irrelevant.  The oracle's fp32
+    mean is within 1e-6 of it."""
+    from patchcore.pipeline import run_category
+    from oracle import alpha as oa
+    images, train = _inputs()
+    ref = run_category(ToyOps(), images, "unsupervised", tau=1.0)
+    one_rank_blocked = run_category(ToyOps(), images, "unsupervised", tau=1.0, budget=2 * 2 * 12 * 4)
+    assert torch.equal(one_rank_blocked["w_loc"], ref["w_loc"])
+    w_oracle = oa.weights_unsupervised(ToyOps().embed(images))
+    np.testing.assert_allclose(ref["w_loc"].numpy(), w_oracle.numpy(), rtol=2e-6, atol=2e-6)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, os.path.join(d, "rdzv"), "unsupervised", d, schedule, budget), nprocs=world,
+                 join=True)
+        for r in range(world):
+            np.testing.assert_array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].numpy())
+            np.testing.assert_array_equal(np.load(os.path.join(d, "X_%d.npy" % r)), ref["X"])
+
+
+def test_supervised_ring_with_sub_blocks():
+    from patchcore.pipeline import run_category
+    images, train = _inputs()
+    ref = run_category(ToyOps(), images, "supervised", tau=1.0, train_images=train, train_ratio=1.0)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(3, os.path.join(d, "rdzv"), "supervised", d, "auto", 2 * 2 * 12 * 4), nprocs=3, join=True)
+        for r in range(3):
+            np.testing.assert_array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].numpy())
 
 
 def test_all_gather_rows_single_process_passthrough():

@@ -80,6 +80,33 @@ def test_shard_bounds_and_bank():
     assert len(select_bank(60, 42, 2.0)) == 60 and len(select_bank(60, 42, 0.5)) == 21
 
 
+def test_unsupervised_block_schedule_covers_every_pair_once():
+    """Ring schedule with symmetric halving (pipeline.unsup_schedule): over all ranks, every ordered pair of
+    distinct images - and every image against itself inside its symmetric block - is produced exactly once,
+    for shard counts that do and do not divide N, empty shards, even world sizes (the split step G/2) and
+    sub-block sizes from 1 image to 'everything'."""
+    from patchcore.pipeline import unsup_schedule, shard_bounds, block_images
+    for n in (0, 1, 2, 3, 7, 16, 83):
+        for world in (1, 2, 3, 4, 5, 8):
+            for c in (1, 2, 5, 1000):
+                b = shard_bounds(n, world)
+                cov = np.zeros((n, n), int)
+                for r in range(world):
+                    for it in unsup_schedule(b, r, c):
+                        (a0, a1) = it[2]
+                        assert b[r][0] <= a0 and a1 <= b[r][1] and a1 - a0 <= c       # keys are always local
+                        if it[0] == "sym":
+                            cov[a0:a1, a0:a1] += 1
+                        else:
+                            (b0, b1) = it[3]
+                            src = (r + it[1]) % world
+                            assert b[src][0] <= b0 and b1 <= b[src][1] and b1 - b0 <= c
+                            cov[a0:a1, b0:b1] += 1
+                            cov[b0:b1, a0:a1] += 1
+                assert (cov == 1).all(), (n, world, c)
+    assert block_images(784, 1 << 30) == 585 and block_images(784, 100) == 1
+
+
 def test_artefact_paths_match_reference_scheme():
     main, test_mod = _examples()
     d = main.artefact_dir("outputs/mvtec_ad/dino_vitbase8/unsupervised", ["blocks.10", "blocks.11"], 2048, 4096, 2, 1)

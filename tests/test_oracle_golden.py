@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from _synth import clustered_embeddings, gaussish_tensor
+from _synth import clustered_embeddings, gaussish_tensor, dino_like_statistics
 
 
 # --------------------------------------------------------------------- helpers
@@ -23,6 +23,26 @@ def _seed0_vit(depth=12):
 
 
 # ------------------------------------------------------------------------ ViT
+def test_oracle_vit_with_dino_like_statistics(golden):
+    """The reference's vit_base on weights with outlier channels, LN gains in [0.2, 5], non-zero biases and
+    heavy-tailed matrices (tests/_synth.py::dino_like_statistics; golden written by make_golden.py --dino):
+    the oracle restatement reproduces its block-10/11 outputs (|x| up to 112) to fp32 round-off."""
+    from oracle import vit as ovit
+    g = golden("vit_forward_dino_stats.npz")
+    sd = dino_like_statistics(_seed0_vit().state_dict())
+    names = sorted(sd.keys())
+    for name, chk in zip(names, g["weight_checks"]):           # the recipe rebuilds the same weights
+        t = sd[name].double().flatten()
+        np.testing.assert_array_equal([t.sum().item(), (t * t).sum().item(), t[0].item(), t[-1].item()], chk, err_msg=name)
+    images = torch.from_numpy(gaussish_tensor((2, 3, 224, 224), salt=11, scale=1.7))
+    taps = ovit.forward_taps(sd, images, taps=(10, 11))
+    toks = g["tokens"]
+    for tap, key in ((10, "f10"), (11, "f11")):
+        ref = g[key]
+        np.testing.assert_allclose(taps[tap][:, toks].numpy(), ref, rtol=2e-5, atol=2e-5)
+        assert abs(taps[tap].abs().max().item() - g["absmax"][tap - 10]) <= 1e-3
+
+
 def test_seeded_init_reproduces_reference_weights(golden):
     """Same RNG draws, same order as the reference's vit_base(patch_size=8) under seed 0:
     per-tensor sum / sum-of-squares / first / last element match the reference's."""

@@ -99,3 +99,52 @@ def test_more_ranks_than_images(dev):
             a = np.load(os.path.join(d, "alpha_%d.npy" % r))
             assert a.shape == (2, 1, 784)
             np.testing.assert_allclose(a, ref["alpha"].cpu().numpy(), rtol=2e-4, atol=1e-8)
+
+
+def _worker_engine(rank, world, init_file, mode, out_dir, schedule, budget):
+    """The alpha engine alone (embeddings given), so that ranks can be compared BIT FOR BIT."""
+    sys.path[:0] = [ROOT, MODELS, os.path.join(ROOT, "tests")]
+    from patchcore.pipeline import HipOps, run_category
+    from _synth import clustered_embeddings
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    Zs, _ = clustered_embeddings(7, 100, 256, 3, salt=51)
+    Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=52)
+    out = run_category(ops, torch.from_numpy(Zs).to(dev), mode, tau=1.0, train_images=torch.from_numpy(Zb).to(dev),
+                       schedule=schedule, budget=budget)
+    np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].cpu().numpy())
+    np.save(os.path.join(out_dir, "w_%d.npy" % rank), out["w_loc"].cpu().numpy())
+    np.save(os.path.join(out_dir, "X_%d.npy" % rank), out["X"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,schedule,budget", [
+    (2, "unsupervised", "ring", 2 * 2 * 100 * 4),      # key buffers of 2 images: streaming + sub-blocks + the split step
+    (3, "unsupervised", "ring", 1 * 1 * 100 * 4),      # odd world, 1-image blocks, a short last shard
+    (2, "unsupervised", "slices", 1 << 30),             # all-gathered packed shards + sliced symmetric launch
+    (3, "supervised", "auto", 2 * 2 * 100 * 4),         # bank shards round the ring
+])
+def test_streaming_schedules_match_one_rank_bitwise(dev, world, mode, schedule, budget):
+    """Two / three real ranks on one GPU with a forced tiny key-buffer budget, so that shard streaming,
+    sub-blocking, symmetric halving and the int64 all-reduce all engage: alpha, w and X are BIT-EQUAL to the
+    one-rank, one-launch result (the sum over key images is fixed point, so no order can change it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patchcore.pipeline import HipOps, run_category, shard_bounds
+    from _synth import clustered_embeddings
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    Zs, _ = clustered_embeddings(7, 100, 256, 3, salt=51)
+    Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=52)
+    ref = run_category(ops, torch.from_numpy(Zs).to(dev), mode, tau=1.0, train_images=torch.from_numpy(Zb).to(dev))
+    bounds = shard_bounds(7, world)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_engine, args=(world, os.path.join(d, "rdzv"), mode, d, schedule, budget), nprocs=world, join=True)
+        for r in range(world):
+            assert np.array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].cpu().numpy()), r
+            assert np.array_equal(np.load(os.path.join(d, "X_%d.npy" % r)), ref["X"]), r
+            lo, hi = bounds[r]
+            assert np.array_equal(np.load(os.path.join(d, "w_%d.npy" % r)), ref["w_loc"][lo:hi].cpu().numpy()), r
