@@ -1,0 +1,291 @@
+// Agglomerative (Ward) clustering and the clustering scores on gfx950 - SURVEY.md section 8 row f1.
+//
+// Reference: examples/test.py:193-195 `cluster.AgglomerativeClustering(n_clusters=len(set(label)))`
+//   -> sklearn ward_tree -> scipy.cluster.hierarchy.ward -> pdist + _hierarchy.nn_chain (scipy 1.10 pinned by
+//   the reference, 1.15 in this image: same algorithm), and :218-220 sklearn's normalized_mutual_info_score /
+//   adjusted_rand_score.  The pairwise distances come from ac_pdist (alpha.hip); this file restates
+//     * scipy's nearest-neighbour-chain linkage for method="ward" - chain order, tie rules (strict <, the
+//       previous chain element preferred, lowest index first), the Lance-Williams update
+//         d(i, x+y) = sqrt((n_i+n_x) t d_ix^2 + (n_i+n_y) t d_iy^2 - n_i t d_xy^2),  t = 1 / (n_x+n_y+n_i)
+//       in the same operation order, the stable sort of the merges by distance and the union-find relabelling
+//       (scipy/cluster/_hierarchy.pyx: nn_chain, _ward, label, LinkageUnionFind) - so the linkage matrix Z is
+//       BIT-IDENTICAL to scipy's on the same condensed distances (tests/test_cluster_gpu.py);
+//     * sklearn's contingency-matrix NMI (arithmetic normaliser) and ARI (pair confusion matrix).
+//
+// The chain is inherently sequential (n-1 merges, ~3 nearest-neighbour scans + one row update each); every scan
+// and every update is O(n) and runs across the 1024 threads of ONE workgroup over a full n x n copy of the
+// distance matrix (row reads are contiguous; the matrix - 800 MB at n = 10 000 - lives in HBM / MALL).  That is
+// ~10x scipy at n = 10 000 and never leaves the device between pdist and the scores.
+#include "common.h"
+
+#include <limits.h>
+
+// ------------------------------------------------------------------ condensed -> square
+__global__ void condensed_to_square_kernel(const double* __restrict__ c, int n, double* __restrict__ D) {
+  const size_t total = (size_t)n * n;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+    if (i == j) { D[e] = 0.0; continue; }
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    D[e] = c[(size_t)a * n - (size_t)a * (a + 1) / 2 + (b - a - 1)];
+  }
+}
+
+__device__ inline void argmin_take(double& d, int& i, double d2, int i2) {
+  if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+}
+
+// ------------------------------------------------------------------ nearest-neighbour chain (one workgroup)
+__global__ __launch_bounds__(1024) void ward_nn_chain_kernel(double* __restrict__ D, int n, int* __restrict__ size,
+                                                             int* __restrict__ chain, double* __restrict__ Zraw) {
+  __shared__ double red_d[16];
+  __shared__ int red_i[16];
+  __shared__ int sh_x, sh_prev, sh_y, sh_len, sh_first, sh_done, sh_nx, sh_ny;
+  __shared__ double sh_cur;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < n; i += 1024) size[i] = 1;
+  if (tid == 0) { sh_len = 0; sh_first = 0; }
+  __syncthreads();
+  for (int k = 0; k < n - 1; ++k) {
+    if (tid == 0 && sh_len == 0) {                 // start a new chain at the first live cluster
+      int f = sh_first;
+      while (size[f] == 0) ++f;
+      sh_first = f;
+      chain[0] = f;
+      sh_len = 1;
+    }
+    __syncthreads();
+    for (;;) {                                      // extend the chain until two clusters are mutual neighbours
+      if (tid == 0) {
+        const int len = sh_len, x = chain[len - 1];
+        sh_x = x;
+        sh_prev = len > 1 ? chain[len - 2] : -1;
+        sh_cur = len > 1 ? D[(size_t)x * n + chain[len - 2]] : __builtin_inf();
+      }
+      __syncthreads();
+      const int x = sh_x;
+      const double* row = D + (size_t)x * n;
+      double bd = __builtin_inf();
+      int bi = INT_MAX;
+      for (int i = tid; i < n; i += 1024) {
+        if (size[i] == 0 || i == x) continue;
+        const double d = row[i];
+        if (d < bd) { bd = d; bi = i; }             // ascending i per thread: first minimum wins
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double d2 = __shfl_xor(bd, o, 64);
+        const int i2 = __shfl_xor(bi, o, 64);
+        argmin_take(bd, bi, d2, i2);
+      }
+      if (lane == 0) { red_d[wv] = bd; red_i[wv] = bi; }
+      __syncthreads();
+      if (tid == 0) {
+        double d = red_d[0];
+        int i = red_i[0];
+        for (int w = 1; w < 16; ++w) argmin_take(d, i, red_d[w], red_i[w]);
+        int y = sh_prev;
+        double cur = sh_cur;
+        if (d < cur) { cur = d; y = i; }            // strict: ties keep the previous chain element
+        const int len = sh_len;
+        if (len > 1 && y == sh_prev) { sh_done = 1; }
+        else { chain[len] = y; sh_len = len + 1; sh_done = 0; }
+        sh_y = y;
+        sh_cur = cur;
+      }
+      __syncthreads();
+      if (sh_done) break;
+    }
+    // merge x = chain top and y = its predecessor; fastcluster convention x < y
+    int x = sh_x, y = sh_y;
+    const double dxy = sh_cur;
+    if (x > y) { const int t = x; x = y; y = t; }
+    if (tid == 0) {
+      sh_len -= 2;
+      sh_nx = size[x];
+      sh_ny = size[y];
+    }
+    __syncthreads();
+    const int nx = sh_nx, ny = sh_ny;
+    if (tid == 0) {
+      double* z = Zraw + (size_t)k * 4;
+      z[0] = (double)x; z[1] = (double)y; z[2] = dxy; z[3] = (double)(nx + ny);
+      size[x] = 0;                                  // x is dropped, y becomes the merged cluster
+      size[y] = nx + ny;
+    }
+    __syncthreads();
+    const double* rx = D + (size_t)x * n;
+    double* ry = D + (size_t)y * n;
+    for (int i = tid; i < n; i += 1024) {
+      const int ni = size[i];
+      if (ni == 0 || i == y) continue;
+      const double dxi = rx[i], dyi = ry[i];
+      const double t = 1.0 / (double)(nx + ny + ni);
+      const double v = sqrt((double)(ni + nx) * t * dxi * dxi + (double)(ni + ny) * t * dyi * dyi - (double)ni * t * dxy * dxy);
+      ry[i] = v;
+      D[(size_t)i * n + y] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ stable sort by distance + relabel
+// rank[i] = #{j : d_j < d_i or (d_j == d_i and j < i)}: the position numpy's stable argsort gives merge i.
+__global__ void rank_sort_kernel(const double* __restrict__ Zraw, int m, double* __restrict__ Zs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const double di = Zraw[(size_t)i * 4 + 2];
+  int r = 0;
+  for (int j = 0; j < m; ++j) {
+    const double dj = Zraw[(size_t)j * 4 + 2];
+    r += (dj < di || (dj == di && j < i)) ? 1 : 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) Zs[(size_t)r * 4 + c] = Zraw[(size_t)i * 4 + c];
+}
+
+// scipy's label(): walk the sorted merges with a union-find whose roots carry the new cluster ids n, n+1, ...
+__global__ void relabel_kernel(double* __restrict__ Z, int n, int* __restrict__ parent, int* __restrict__ csize) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 0; i < 2 * n - 1; ++i) { parent[i] = i; csize[i] = 1; }
+  int next_label = n;
+  auto find = [&](int x) {
+    int p = x;
+    while (parent[x] != x) x = parent[x];
+    while (parent[p] != x) { const int q = parent[p]; parent[p] = x; p = q; }
+    return x;
+  };
+  for (int i = 0; i < n - 1; ++i) {
+    const int x = (int)Z[(size_t)i * 4], y = (int)Z[(size_t)i * 4 + 1];
+    const int xr = find(x), yr = find(y);
+    Z[(size_t)i * 4] = (double)(xr < yr ? xr : yr);
+    Z[(size_t)i * 4 + 1] = (double)(xr < yr ? yr : xr);
+    parent[xr] = next_label;
+    parent[yr] = next_label;
+    const int s = csize[xr] + csize[yr];
+    csize[next_label] = s;
+    ++next_label;
+    Z[(size_t)i * 4 + 3] = (double)s;
+  }
+}
+
+extern "C" size_t ac_ward_workspace_bytes(int64_t n) {
+  if (n < 2) return 256;
+  return align_up((size_t)n * n * 8, 256) + align_up((size_t)n * 4, 256) * 2 + align_up((size_t)(n - 1) * 4 * 8, 256) +
+         align_up((size_t)(2 * n - 1) * 4, 256) * 2 + 256;
+}
+
+extern "C" int ac_ward_linkage(const double* condensed, int64_t n, double* Z, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(n >= 0 && n <= 46000, "ac_ward_linkage: n=%lld out of range (0..46000)", (long long)n);
+  if (n < 2) return AC_OK;
+  AC_REQUIRE(condensed && Z && ws, "ac_ward_linkage: null pointer");
+  if (ws_bytes < ac_ward_workspace_bytes(n)) return ac_fail(AC_EWORKSPACE, "ac_ward_linkage: workspace too small");
+  Arena ar(ws, ws_bytes);
+  double* D = ar.take<double>((size_t)n * n);
+  int* size = ar.take<int>((size_t)n);
+  int* chain = ar.take<int>((size_t)n);
+  double* Zraw = ar.take<double>((size_t)(n - 1) * 4);
+  int* parent = ar.take<int>((size_t)(2 * n - 1));
+  int* csize = ar.take<int>((size_t)(2 * n - 1));
+  if (!ar.ok()) return ac_fail(AC_EWORKSPACE, "ac_ward_linkage: workspace carve failed");
+  const size_t total = (size_t)n * n;
+  hipLaunchKernelGGL(condensed_to_square_kernel, dim3((unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535)),
+                     dim3(256), 0, stream, condensed, (int)n, D);
+  hipLaunchKernelGGL(ward_nn_chain_kernel, dim3(1), dim3(1024), 0, stream, D, (int)n, size, chain, Zraw);
+  const int m = (int)n - 1;
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, Zraw, m, Z);
+  hipLaunchKernelGGL(relabel_kernel, dim3(1), dim3(64), 0, stream, Z, (int)n, parent, csize);
+  return ac_check_launch("ac_ward_linkage");
+}
+
+// ------------------------------------------------------------------ contingency matrix, NMI, ARI
+__global__ void contingency_kernel(const int* __restrict__ a, const int* __restrict__ b, int64_t n, int ka, int kb,
+                                   unsigned long long* __restrict__ C, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int u = a[i], v = b[i];
+    if (u < 0 || u >= ka || v < 0 || v >= kb) { *bad = 1; continue; }
+    atomicAdd(&C[(size_t)u * kb + v], 1ull);
+  }
+}
+
+// sklearn.metrics.normalized_mutual_info_score (average_method="arithmetic") and adjusted_rand_score from the
+// contingency matrix (sklearn/metrics/cluster/_supervised.py: mutual_info_score, entropy, pair_confusion_matrix).
+__global__ void scores_kernel(const unsigned long long* __restrict__ C, int ka, int kb, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double N = 0.0, sum_sq = 0.0;
+  int rows = 0, cols = 0;
+  for (int u = 0; u < ka; ++u) {
+    double r = 0.0;
+    for (int v = 0; v < kb; ++v) { const double c = (double)C[(size_t)u * kb + v]; r += c; sum_sq += c * c; }
+    N += r;
+    rows += r > 0.0;
+  }
+  for (int v = 0; v < kb; ++v) {
+    double c = 0.0;
+    for (int u = 0; u < ka; ++u) c += (double)C[(size_t)u * kb + v];
+    cols += c > 0.0;
+  }
+  const double eps = 2.220446049250313e-16;
+  // entropies and mutual information, natural logarithm
+  double hu = 0.0, hv = 0.0, mi = 0.0, dot_k = 0.0, dot_c = 0.0;
+  const double logN = log(N);
+  for (int u = 0; u < ka; ++u) {
+    double r = 0.0;
+    for (int v = 0; v < kb; ++v) r += (double)C[(size_t)u * kb + v];
+    if (r > 0.0) hu -= (r / N) * (log(r) - logN);
+  }
+  for (int v = 0; v < kb; ++v) {
+    double c = 0.0;
+    for (int u = 0; u < ka; ++u) c += (double)C[(size_t)u * kb + v];
+    if (c > 0.0) hv -= (c / N) * (log(c) - logN);
+  }
+  for (int u = 0; u < ka; ++u) {
+    double r = 0.0;
+    for (int v = 0; v < kb; ++v) r += (double)C[(size_t)u * kb + v];
+    for (int v = 0; v < kb; ++v) {
+      const double nij = (double)C[(size_t)u * kb + v];
+      double c = 0.0;
+      for (int w = 0; w < ka; ++w) c += (double)C[(size_t)w * kb + v];
+      dot_k += nij * c;                     // contingency.dot(n_k).sum()
+      dot_c += nij * r;                     // contingency.T.dot(n_c).sum()
+      if (nij > 0.0) {
+        const double nm = nij / N;
+        const double term = nm * (log(nij) - logN) + nm * (-log(r * c) + logN + logN);
+        mi += fabs(term) < eps ? 0.0 : term;
+      }
+    }
+  }
+  if (mi < 0.0) mi = 0.0;
+  double nmi;
+  if ((rows == 1 && cols == 1) || (rows == 0 && cols == 0)) nmi = 1.0;
+  else if (fabs(mi) < eps) nmi = 0.0;       // sklearn: "if mi is ~0 the score is 0"
+  else {
+    double normalizer = 0.5 * (hu + hv);
+    if (normalizer < eps) normalizer = eps;
+    nmi = mi / normalizer;
+  }
+  // pair confusion matrix
+  const double tp = sum_sq - N, fp = dot_k - sum_sq, fn = dot_c - sum_sq, tn = N * N - fp - fn - sum_sq;
+  double ari;
+  if (fn == 0.0 && fp == 0.0) ari = 1.0;
+  else ari = 2.0 * (tp * tn - fn * fp) / ((tp + fn) * (fn + tn) + (tp + fp) * (fp + tn));
+  out[0] = nmi;
+  out[1] = ari;
+}
+
+extern "C" int ac_cluster_scores(const int32_t* labels_true, const int32_t* labels_pred, int64_t n, int k_true, int k_pred,
+                                 uint64_t* contingency, double* scores, int32_t* bad_label_flag, void* stream_) {
+  hipStream_t stream = as_stream(stream_);
+  AC_REQUIRE(labels_true && labels_pred && contingency && scores && bad_label_flag, "ac_cluster_scores: null pointer");
+  AC_REQUIRE(n > 0 && k_true > 0 && k_pred > 0 && k_true <= 4096 && k_pred <= 4096, "ac_cluster_scores: bad shape");
+  if (hipMemsetAsync(contingency, 0, (size_t)k_true * k_pred * 8, stream) != hipSuccess ||
+      hipMemsetAsync(bad_label_flag, 0, 4, stream) != hipSuccess)
+    return ac_fail(AC_ELAUNCH, "ac_cluster_scores: hipMemsetAsync failed");
+  hipLaunchKernelGGL(contingency_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                     stream, labels_true, labels_pred, n, k_true, k_pred, reinterpret_cast<unsigned long long*>(contingency),
+                     bad_label_flag);
+  hipLaunchKernelGGL(scores_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const unsigned long long*>(contingency),
+                     k_true, k_pred, scores);
+  return ac_check_launch("ac_cluster_scores");
+}

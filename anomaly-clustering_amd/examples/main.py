@@ -63,7 +63,7 @@ def _dataset(path, category, split, dataset):
 
 def make_category_data(path, category, pretrain_embed_dimension, target_embed_dimension, backbone_names,
                        layers_to_extract_from, patchsize, save_path, train_ratio=1.0, tau=1, supervised="unsupervised",
-                       dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=32):
+                       dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=32, cache=None):
     print("{:-^80}".format(category + ' start ' + supervised))
     faiss_on_gpu = True
     faiss_num_workers = 4
@@ -100,12 +100,18 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
     # ONE pass over each split: decode on the host, resize / crop / normalise on the GPU, and collect the per-image
     # records (what test.py reads as `info`: the item dicts minus pixels, collated with batch size 1) on the way.
     # The reference walks the test set twice with batch size 1 (main.py:254-262, :266).
-    images, info = test_dataset.load_category(device)
+    # `cache` (a dict the caller keeps per category): the loaded test set and its embeddings Z are the same for
+    # every mode, so `--supervised both` decodes and embeds the test images once.
+    cache = {} if cache is None else cache
+    if "images" not in cache:
+        cache["images"], cache["info"] = test_dataset.load_category(device)
+    images, info = cache["images"], cache["info"]
     train_images = None
     if supervised == "supervised":
         train_images, _ = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset).load_category(device)
     out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
-                       train_images=train_images, train_ratio=train_ratio, want_pdist=False)
+                       train_images=train_images, train_ratio=train_ratio, want_pdist=False, Z_loc=cache.get("Z_loc"))
+    cache["Z_loc"] = out["Z_loc"]
     # `tau` may be a list (a sweep): embeddings and patch distances were computed once; one artefact per tau
     taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
     rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
@@ -162,7 +168,10 @@ def main(argv=None):
         os.makedirs(save_path, exist_ok=True)
         with open(os.path.join(save_path, "WEIGHTS_SOURCE.txt"), "w") as f:     # random-init runs stay recognisable
             f.write(str(getattr(backbone, "weights_source", "unknown")) + "\n")
-        for category in (args.categories or _CLASSNAMES):
+    for category in (args.categories or _CLASSNAMES):
+        cache = {}                                       # test images + embeddings shared by the modes of a category
+        for supervised in modes:
+            save_path = args.output_dir + "/" + args.dataset + "/" + args.backbone_names[0] + "/" + supervised
             results[(supervised, category)] = make_category_data(
                 path=args.path, category=category, pretrain_embed_dimension=args.pretrain_embed_dimension,
                 target_embed_dimension=args.target_embed_dimension, backbone_names=args.backbone_names,
@@ -170,7 +179,7 @@ def main(argv=None):
                 tau=(args.tau_list if args.tau_list else args.tau), train_ratio=args.train_ratio,
                 supervised=supervised, dataset=args.dataset,
                 info_dir=args.output_dir + "/" + args.dataset + "/info", backbone=backbone,
-                batch_size=args.batch_size)
+                batch_size=args.batch_size, cache=cache)
     return results
 
 

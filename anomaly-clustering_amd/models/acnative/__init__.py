@@ -57,6 +57,9 @@ SIGNATURES = {
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "ac_ward_workspace_bytes": (_sz, [_i64]),
+    "ac_ward_linkage": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "ac_cluster_scores": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -522,3 +525,35 @@ def pdist(X):
     out = torch.empty((N * (N - 1) // 2,), dtype=torch.float64, device=X.device)
     _check(lib().ac_pdist(p, N, D, out.data_ptr(), _stream()))
     return out
+
+
+# ---------------------------------------------------------------- clustering
+def ward_linkage(condensed, n):
+    """scipy.cluster.hierarchy.linkage(y, "ward") on the device: condensed fp64 distances (as pdist() returns
+    them) -> Z fp64 [n-1, 4], bit-identical to scipy's."""
+    p = _dev(condensed, torch.float64, "condensed")
+    if condensed.numel() != n * (n - 1) // 2:
+        raise ValueError("condensed has %d entries, n = %d needs %d" % (condensed.numel(), n, n * (n - 1) // 2))
+    Z = torch.empty((max(n - 1, 0), 4), dtype=torch.float64, device=condensed.device)
+    if n < 2:
+        return Z
+    nbytes = lib().ac_ward_workspace_bytes(n)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=condensed.device)      # ~8 n^2 bytes: not kept around
+    _check(lib().ac_ward_linkage(p, n, Z.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    return Z
+
+
+def cluster_scores(labels_true, labels_pred, k_true, k_pred):
+    """int32 device label vectors -> (NMI, ARI, contingency int64 [k_true, k_pred] on the host)."""
+    a, b = _dev(labels_true, torch.int32, "labels_true"), _dev(labels_pred, torch.int32, "labels_pred")
+    n = labels_true.numel()
+    if labels_pred.numel() != n or n == 0:
+        raise ValueError("label vectors must be non-empty and of equal length")
+    C = torch.empty((k_true, k_pred), dtype=torch.int64, device=labels_true.device)
+    scores = torch.empty(2, dtype=torch.float64, device=labels_true.device)
+    bad = torch.empty(1, dtype=torch.int32, device=labels_true.device)
+    _check(lib().ac_cluster_scores(a, b, n, k_true, k_pred, C.data_ptr(), scores.data_ptr(), bad.data_ptr(), _stream()))
+    if int(bad.item()):
+        raise ValueError("a label lies outside [0, k)")
+    s = scores.cpu()
+    return float(s[0]), float(s[1]), C.cpu().numpy()

@@ -1,18 +1,18 @@
 """Weighted-average embeddings -> Ward clusters -> Hungarian relabel -> NMI / ARI / F1
 (reference: examples/test.py:109-131 best_map, :176-220 calculate_metrics).
 
-The N x N distance work runs on the GPU (``acnative.pdist``: condensed float64 Euclidean
-distances, the quantity scipy's Ward linkage starts from); the O(N^2) nearest-neighbour-chain
-linkage itself stays on the host in scipy, exactly the routine sklearn's
-AgglomerativeClustering(linkage="ward") calls (ward_tree -> scipy.cluster.hierarchy.ward), fed
-with the precomputed condensed matrix instead of X.  Tree cut, label matching and the three
-scores follow the reference (sklearn metrics; scipy's linear_sum_assignment in place of munkres).
+Everything O(N^2) runs on the GPU: ``acnative.pdist`` (condensed float64 Euclidean distances, the quantity
+scipy's Ward linkage starts from) and ``acnative.ward_linkage`` (the nearest-neighbour-chain linkage itself, a
+restatement of scipy.cluster.hierarchy.linkage(method="ward") - the routine sklearn's AgglomerativeClustering
+reaches through ward_tree - that returns a bit-identical linkage matrix; csrc/cluster.hip).  NMI and ARI come
+from the contingency matrix on the GPU (``acnative.cluster_scores``).  What stays on the host is O(N) or
+O(k^3) glue: the tree cut (sklearn's _hc_cut numbering), the Hungarian relabelling of <= 9 clusters (scipy's
+linear_sum_assignment in place of munkres) and the micro-F1 of the relabelled vector.
 """
 from heapq import heappush, heappushpop
 
 import numpy as np
 import torch
-from scipy.cluster import hierarchy
 from scipy.optimize import linear_sum_assignment
 from sklearn import metrics
 from sklearn.preprocessing import LabelEncoder
@@ -21,10 +21,12 @@ import acnative
 
 
 def ward_children(condensed, n):
-    """Ward linkage on a condensed float64 distance vector -> merge table [n-1, 2] (sklearn's children_)."""
+    """Ward linkage on a condensed float64 distance vector (DEVICE tensor) -> merge table [n-1, 2] (sklearn's
+    children_).  Raises on host data: the linkage has no CPU fallback."""
     if n < 2:
         return np.zeros((0, 2), dtype=np.intp)
-    return hierarchy.linkage(np.asarray(condensed, dtype=np.float64), method="ward")[:, :2].astype(np.intp)
+    Z = acnative.ward_linkage(condensed, n)
+    return Z[:, :2].cpu().numpy().astype(np.intp)
 
 
 def cut_tree(children, n_clusters, n_leaves):
@@ -65,8 +67,7 @@ def agglomerative_ward(X, n_clusters, device=None):
     if n == 1:
         return np.zeros(1, dtype=np.intp)
     condensed = acnative.pdist(X.to(torch.float32).contiguous())    # raises on a CPU tensor: no CPU fallback
-    children = ward_children(condensed.cpu().numpy(), n)
-    return cut_tree(children, n_clusters, n)
+    return cut_tree(ward_children(condensed, n), n_clusters, n)
 
 
 def best_map(L1, L2):
@@ -85,28 +86,36 @@ def best_map(L1, L2):
     return out
 
 
-def metrics_from_labels(label, predict):
-    predict = best_map(label, predict).astype(int)
-    NMI = metrics.normalized_mutual_info_score(label, predict)
-    ARI = metrics.adjusted_rand_score(label, predict)
+def metrics_from_labels(label, predict, device=None):
+    """Ground-truth ids + cluster ids -> NMI, ARI (contingency matrix on the GPU), micro-F1 of the Hungarian-
+    relabelled prediction (reference :197-220).  Returns NMI, ARI, F1, label, predict(relabelled)."""
+    label = np.asarray(label).astype(int)
+    predict = best_map(label, np.asarray(predict)).astype(int)
+    if device is None:       # no GPU: acnative.cluster_scores raises on the host tensors (no CPU fallback)
+        device = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
+    lt = torch.from_numpy(label.astype(np.int32)).to(device)
+    # best_map writes ground-truth label VALUES into predict: both vectors live in [0, max label]
+    k = int(max(label.max(), predict.max())) + 1
+    NMI, ARI, _ = acnative.cluster_scores(lt, torch.from_numpy(predict.astype(np.int32)).to(device), k, k)
     F1 = metrics.f1_score(label, predict, average="micro")
     return NMI, ARI, F1, label, predict
 
 
 def cluster_metrics_from_pdist(condensed, anomaly_names):
-    """The same chain from distances that are already computed (bench.py, pipeline output): condensed float64
-    Euclidean distances of ALL images (tensor or array) + per-image anomaly strings.  "combined" images are
-    dropped by selecting the sub-matrix (distances between the kept images do not change)."""
-    from scipy.spatial.distance import squareform
-    d = condensed.detach().cpu().numpy() if isinstance(condensed, torch.Tensor) else np.asarray(condensed)
+    """The same chain from distances that are already on the device (bench.py, pipeline output): condensed
+    float64 Euclidean distances of ALL images + per-image anomaly strings.  "combined" images are dropped by
+    selecting the sub-matrix (distances between the kept images do not change)."""
     keep = [i for i, a in enumerate(anomaly_names) if a != "combined"]
     names = [anomaly_names[i] for i in keep]
-    if len(keep) != len(anomaly_names):
-        d = squareform(squareform(d, checks=False)[np.ix_(keep, keep)], checks=False)
+    n_all, n = len(anomaly_names), len(keep)
+    if n != n_all:
+        idx = torch.tensor(keep, device=condensed.device)
+        iu = torch.triu_indices(n, n, 1, device=condensed.device)
+        a, b = idx[iu[0]], idx[iu[1]]
+        condensed = condensed[a * n_all - a * (a + 1) // 2 + (b - a - 1)].contiguous()
     label = LabelEncoder().fit_transform(names).astype(int)
-    n = len(keep)
-    predict = cut_tree(ward_children(d, n), len(set(label)), n) if n > 1 else np.zeros(n, dtype=np.intp)
-    return metrics_from_labels(label, predict)
+    predict = cut_tree(ward_children(condensed, n), len(set(label)), n) if n > 1 else np.zeros(n, dtype=np.intp)
+    return metrics_from_labels(label, predict, condensed.device)
 
 
 def cluster_metrics(X, anomaly_names, device=None):
@@ -117,4 +126,4 @@ def cluster_metrics(X, anomaly_names, device=None):
     Xk = np.asarray(X)[keep]
     label = LabelEncoder().fit_transform(names).astype(int)
     predict = agglomerative_ward(Xk, len(set(label)), device)
-    return metrics_from_labels(label, predict)
+    return metrics_from_labels(label, predict, device)

@@ -344,12 +344,15 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
 
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
-                 schedule="auto"):
+                 schedule="auto", Z_loc=None):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
     budget / schedule: memory budget of one matrix of minima and the unsupervised schedule ("auto", "slices",
     "ring") - results do not depend on either.
+    Z_loc: the rank's embeddings from an earlier call on the same images (out["Z_loc"]): Z does not depend on
+    the mode, so a run over several modes embeds the test set once (the reference re-embeds per mode and per tau,
+    examples/main.py:346-366).
     Returns dict(alpha fp32 [N, 1, P] on device, X float32 ndarray [N, D], X_dev, pdist (rank 0), bounds)."""
     rank, world = _world(group)
     n = images.shape[0]
@@ -364,7 +367,10 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
             t[name] = t.get(name, 0.0) + (time.perf_counter() - t0)
 
     t0 = time.perf_counter()
-    Z_loc = ops.embed(images[lo:hi])                                   # [n_loc, P, D]
+    if Z_loc is None:
+        Z_loc = ops.embed(images[lo:hi])                               # [n_loc, P, D]
+    elif Z_loc.shape[0] != hi - lo:
+        raise ValueError("Z_loc holds %d images, this rank's shard has %d" % (Z_loc.shape[0], hi - lo))
     mark("embed", t0)
     device = Z_loc.device
 
@@ -411,4 +417,5 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     out["bounds"] = bounds
     out["by_tau"] = by_tau
     out["w_loc"] = w_loc
+    out["Z_loc"] = Z_loc
     return out

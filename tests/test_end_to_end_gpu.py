@@ -156,3 +156,28 @@ def test_tau_sweep_reuses_one_pass(dev, small_model):
             np.testing.assert_allclose(a, a_ref, rtol=1e-4 / min(1.0, tv), atol=1e-6, err_msg="tau=%g" % tv)
     a0 = sweep["by_tau"][0.0]["alpha"].squeeze(1)
     assert torch.all((a0 > 0).sum(1) >= 1) and torch.allclose(a0.sum(1), torch.ones(5, device=dev))
+
+
+def test_cli_both_modes_share_one_embedding_pass(tmp_path, dev, monkeypatch):
+    """`main.py --supervised both --dataset synthetic --categories toothbrush`: the reference's hard-coded loop over
+    both modes (main.py:348).  The test set is loaded and embedded once per category and reused by the second
+    mode; both artefacts equal what separate single-mode runs write, the info pickle is written, and the run is
+    marked as a random-init run."""
+    main, test_mod = _load_examples()
+    out = str(tmp_path / "o")
+    argv = ["--dataset", "synthetic", "--categories", "toothbrush", "--output_dir", out, "--batch_size", "64"]
+    both = main.main(argv + ["--supervised", "both"])
+    assert set(both) == {("unsupervised", "toothbrush"), ("supervised", "toothbrush")}
+    for mode in ("unsupervised", "supervised"):
+        single = main.main(argv + ["--supervised", mode, "--output_dir", out + "_" + mode])
+        a, X = both[(mode, "toothbrush")]
+        a1, X1 = single[(mode, "toothbrush")]
+        assert a.shape == (42, 1, 784) and torch.equal(a, a1) and np.array_equal(X, X1)
+        folder = out + "/synthetic/dino_vitbase8/" + mode
+        assert open(folder + "/WEIGHTS_SOURCE.txt").read().strip() == "random-init(seed=0)"
+        saved = test_mod._safe_load(folder + "/blocks.10_blocks.11_2048_4096_1.0_1.0/matrix_alpha_X_toothbrush_%s.pickle" % mode)
+        assert torch.equal(saved[0], a) and np.array_equal(saved[1], X)
+    info = test_mod._safe_load(out + "/synthetic/info/info_toothbrush.pickle")
+    assert len(info) == 42 and info[0]["anomaly"] == ["defective"] and info[41]["anomaly"] == ["good"]
+    with pytest.raises(FileNotFoundError):                       # a mistyped --path never silently goes synthetic
+        main.main(["--path", str(tmp_path / "nope"), "--categories", "toothbrush", "--output_dir", out])

@@ -14,9 +14,18 @@ from conftest import EXAMPLES
 
 @pytest.fixture()
 def oracle_pdist(monkeypatch):
+    """No GPU here: the three device entry points of the clustering stage are replaced by what they restate
+    (scipy pdist, scipy ward linkage, sklearn NMI / ARI) so that the HOST logic around them can be tested.
+    tests/test_cluster_gpu.py checks the device versions against exactly these."""
     import acnative
     from oracle import cluster as oc
+    from scipy.cluster import hierarchy
+    from sklearn import metrics
     monkeypatch.setattr(acnative, "pdist", lambda X: torch.from_numpy(oc.pdist(X.cpu().numpy())))
+    monkeypatch.setattr(acnative, "ward_linkage",
+                        lambda c, n: torch.from_numpy(hierarchy.linkage(c.cpu().numpy(), method="ward")))
+    monkeypatch.setattr(acnative, "cluster_scores", lambda a, b, ka, kb: (
+        metrics.normalized_mutual_info_score(a.numpy(), b.numpy()), metrics.adjusted_rand_score(a.numpy(), b.numpy()), None))
 
 
 def _examples():
@@ -31,7 +40,7 @@ def _examples():
     return main, test_mod
 
 
-def test_cut_tree_equals_sklearn_cut():
+def test_cut_tree_equals_sklearn_cut(oracle_pdist):
     from sklearn.cluster._agglomerative import _hc_cut
     from scipy.cluster import hierarchy
     from patchcore.clustering import cut_tree, ward_children
@@ -39,7 +48,7 @@ def test_cut_tree_equals_sklearn_cut():
     rng = np.random.default_rng(3)
     for n, k in [(2, 1), (2, 2), (7, 3), (40, 6), (41, 41)]:
         X = rng.normal(size=(n, 5))
-        children = ward_children(pdist(X), n)
+        children = ward_children(torch.from_numpy(pdist(X)), n)
         ref_children = hierarchy.ward(X)[:, :2].astype(np.intp)
         assert np.array_equal(children, ref_children)
         assert np.array_equal(cut_tree(children, k, n), _hc_cut(k, ref_children, n))
@@ -148,6 +157,27 @@ def test_sweep_csv_layout_and_pickle_round_trip(tmp_path, oracle_pdist, golden):
     np.testing.assert_allclose([float(v) for v in rows[4][1:]], g["toothbrush"]["expected"], atol=1e-12)
     np.testing.assert_allclose([float(v) for v in rows[5][1:]], g["grid"]["expected"], atol=1e-12)
     np.testing.assert_allclose([float(v) for v in rows[6][1:]], g["toothbrush"]["expected"], atol=1e-12)
+
+
+def test_alpha_heatmaps(tmp_path):
+    """Reference test.py:158-174: 28x28 alpha -> x8 nearest -> / max; one file per anomaly type."""
+    import PIL.Image
+    main, test_mod = _examples()
+    a = np.full(784, 0.001, dtype=np.float32)
+    a[5 * 28 + 9] = 0.2                                    # the maximum at patch (5, 9)
+    a[0] = 0.1
+    heat = test_mod.alpha_heatmap(a)
+    assert heat.shape == (224, 224) and heat.dtype == np.uint8 and heat.max() == 255
+    assert (heat[40:48, 72:80] == 255).all() and (heat[0:8, 0:8] == 127).all() and heat[8, 8] == 1
+    info = [{"classname": ["grid"], "anomaly": [k], "image_path": ["synthetic://none.png"]} for k in
+            ("bent", "bent", "good", "good", "thread")]
+    alpha = torch.from_numpy(np.stack([a] * 5)).unsqueeze(1)
+    files = test_mod.render_heatmaps("grid", alpha, info, str(tmp_path / "vis"))
+    assert [os.path.basename(f) for f in files] == ["grid_bent.png", "grid_good.png", "grid_thread.png"]
+    im = np.asarray(PIL.Image.open(files[0]))
+    assert im.shape == (224, 3 * 224 + 16, 3) and (im[40:48, 2 * 224 + 16 + 72: 2 * 224 + 16 + 80] == 255).all()
+    with pytest.raises(ValueError):
+        test_mod.alpha_heatmap(np.ones(10))
 
 
 def test_synthetic_dataset_shapes_and_histograms():
