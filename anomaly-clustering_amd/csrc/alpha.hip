@@ -153,12 +153,11 @@ template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetri
 // The all-pairs kernel is gemm_hl2.h's 256x128 ring kernel with two-level accumulation (FLUSH): the only tile
 // whose per-wave state leaves room for the second accumulator that fp32-grade distances need (DESIGN.md
 // section 2; the 256x256 stream without it is 10 % faster and 6x further from the fp64 truth).
-// L2 window of the rasterisation (tile rows per group): in the folded symmetric grid tile (p, c) is
-// (tm, tn) = (p, 2p + c), so a window of R rows x C columns touches R row panels but 2R - 2 + C column
-// panels and a flat window re-reads least (FETCH_SIZE confirmed: 4 rows -28 % L2-miss bytes vs 8).
+// L2 window of the rasterisation: 6 tile rows per group (the 32 workgroups an XCD runs at a time then share 6 row
+// panels and ~6 column panels); same-box A/B over 2..16 rows and two tile orders: profiles/r02_raster_ab.txt.
 static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream,
                            int part = 0, int nparts = 1) {
-  const int group_m = epi.symmetric ? 4 : 8;
+  const int group_m = 6;
 #ifdef AC_EXPERIMENTAL
   const int v = epi.two_way ? 0 : ac_gemm_policy();
   if (v == 101 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);

@@ -67,26 +67,67 @@ __device__ inline int tile_off(int row, int lc) { return row * 128 + ((lc ^ ((ro
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Map a linear tile id to (tm, tn); false when the id is a hole of the folded symmetric grid.
+// Tiles of the upper triangle of a symmetric problem on 256-row x 128-column tiles: in units of 128-blocks a
+// tile holds row blocks {2tm, 2tm+1} and column block tn, so tile row p needs the columns tn >= 2p:
+// cnt(p) = Tn - 2p tiles, F(p) = p Tn - p (p - 1) tiles in the rows above p.
+__host__ __device__ inline long long tri_rows_before(int p, int Tn) { return (long long)p * Tn - (long long)p * (p - 1); }
+
+// Linear order of those tiles, made for the L2: groups of G tile rows; inside a group the ACTUAL column tn runs
+// slowest and the row fastest, so the 32 workgroups an XCD runs at one time (a contiguous run of this order)
+// cover G row panels x 32/G column panels that they all share.  (Round 1 folded the triangle into a rectangle
+// first; a window of folded columns then touched 2G - 2 + 32/G different column panels.  Same-box A/B,
+// profiles/r02_raster_ab.txt: -2 % time, G = 6 best.)
+// Equal work per XCD and per GPU slice needs no folding: the order is cut into equal runs by tile count.
+__device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn) {
+  // row p with F(p) <= lin < F(p + 1): root of p^2 - (Tn + 1) p + lin = 0, then the group it belongs to
+  const double b = (double)Tn + 1.0;
+  int p = (int)((b - sqrt(fmax(b * b - 4.0 * (double)lin, 0.0))) * 0.5);
+  p = max(0, min(p, Tm - 1));
+  while (p > 0 && tri_rows_before(p, Tn) > lin) --p;
+  while (p + 1 < Tm && tri_rows_before(p + 1, Tn) <= lin) ++p;
+  const int p0 = (p / G) * G, gsz = min(G, Tm - p0);
+  int w = lin - (int)tri_rows_before(p0, Tn);           // index inside the group
+  // column c = tn - 2 p0 has v(c) = min(gsz, c/2 + 1) valid rows; the ragged head is 2 (gsz - 1) columns and
+  // gsz (gsz - 1) tiles long, every later column is full
+  const int head = gsz * (gsz - 1);
+  int c, r;
+  if (w >= head) {
+    w -= head;
+    c = 2 * (gsz - 1) + w / gsz;
+    r = w - (w / gsz) * gsz;
+  } else {
+    c = 0;
+    for (;;) {                                          // at most 2 (G - 1) steps
+      const int v = c / 2 + 1;
+      if (w < v) break;
+      w -= v;
+      ++c;
+    }
+    r = w;
+  }
+  tm = p0 + r;
+  tn = 2 * p0 + c;
+}
+
+__device__ inline int xcd_chunk_lin(int id, long long total) {
+  // blocks are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of the linear order
+  const int q = (int)(total >> 3), r = (int)(total & 7), xcd = id & 7, slot = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// Map a linear tile id to (tm, tn).  Symmetric problems: tiles_m / tiles_n are the full tile counts Tm / Tn and
+// the id space is the triangle above.
 template <class Epi>
 __device__ inline bool tile_of(int id, int tiles_m, int tiles_n, int group_m, int M, int N, const Epi& epi,
                                int& tm, int& tn) {
-  gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {
-      // C = C^T on a grid of 256-row x 128-column tiles: in units of 128-blocks a tile holds row
-      // blocks {2tm, 2tm+1} and column block tn; the upper triangle needs the tiles with tn >= 2tm.
-      // Tile row p has Tn - 2p of them; rows p and Tm-1-p together always have 2Tn - 2Tm + 2, so the
-      // tile space is that folded rectangle and every slice of it carries the same amount of work.
-      const int Tm = (M + BM - 1) / BM, Tn = (N + BN - 1) / BN;
-      const int p = tm, c = tn, n1 = Tn - 2 * p;
-      if (c < n1) { tm = p; tn = 2 * p + c; }
-      else {
-        if (2 * p == Tm - 1) return false;          // odd Tm: the middle row is paired with itself
-        tm = Tm - 1 - p; tn = 2 * tm + (c - n1);
-      }
+      const long long total = tri_rows_before(tiles_m, tiles_n);
+      tri_tile(xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m, tm, tn);
+      return true;
     }
   }
+  gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);
   return true;
 }
 
@@ -307,16 +348,15 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl2: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl2: bad part %d/%d", part, nparts);
+  if (group_m < 1) return ac_fail(AC_EINVAL, "gemm_hl2: group_m=%d must be positive", group_m);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  long long total = (long long)tiles_m * tiles_n;
   if constexpr (EpiTraits<Epi>::kSymmetric) {
-    if (epi.symmetric) {                           // folded upper triangle (see tile_of)
+    if (epi.symmetric) {                           // upper triangle only (see tile_of)
       if (M != N) return ac_fail(AC_EINVAL, "gemm_hl2: symmetric epilogue needs M == N");
-      const int Tm = tiles_m, Tn = tiles_n;
-      tiles_m = (Tm + 1) / 2;
-      tiles_n = 2 * Tn - 2 * Tm + 2;
+      total = tri_rows_before(tiles_m, tiles_n);
     }
   }
-  long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl2: grid too large");
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
   if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, FLUSH>), LDS_BYTES, &attr_done)) return rc;

@@ -477,13 +477,22 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     const int vslot = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
     vsrc[j] = Vbase + (size_t)krow * (HD * 4) + vslot * 16;
   }
+  // Keys >= T (the tail of the last tile): their scores are masked to -inf below, so p = 0 - but 0 * V must stay
+  // 0, and the pad rows of the V buffer are never written.  Those lanes fetch row T-1 instead (any finite row
+  // does), which replaces the pad-zeroing kernel of round 1.
   auto dma_tile = [&](int kt) {
     uint8_t* buf = lds + (kt & 1) * ATT_TILE;
+    const bool last = kt == ntiles - 1;               // block-uniform
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int g = wave + 4 * j;
+      const uint8_t* vs = vsrc[j] + (size_t)kt * (ATT_KT * HD * 4);
+      if (last) {
+        const int over = kt * ATT_KT + 4 * g + (lane >> 4) - (T - 1);
+        if (over > 0) vs -= (size_t)over * (HD * 4);
+      }
       __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[j] + (size_t)kt * (ATT_KT * HD * 4)), (lptr_t)(buf + g * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[j] + (size_t)kt * (ATT_KT * HD * 4)), (lptr_t)(buf + 8192 + g * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(buf + 8192 + g * 1024), 16, 0, 0);
     }
   };
   const int pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // pi(r): key held by MFMA row r
@@ -625,16 +634,6 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   }
 }
 
-// zero the pad rows t in [T, Tpad) of every V image (p = 0 there, but 0 * garbage must stay 0)
-__global__ void zero_v_pad_kernel(uint8_t* v, int images, int T, int Tpad) {
-  const int per = (Tpad - T) * (HD * 4) / 16;           // 16-byte pieces per image
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= images * per) return;
-  const int img = i / per, piece = i - img * per;
-  u32x4 z = {0u, 0u, 0u, 0u};
-  *reinterpret_cast<u32x4*>(v + ((size_t)img * Tpad + T) * (HD * 4) + (size_t)piece * 16) = z;
-}
-
 struct VitWs {
   uint8_t *h, *q, *k, *v, *o, *g, *cols;
 };
@@ -721,10 +720,6 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
   const uint8_t* wqkv = static_cast<const uint8_t*>(w->qkv_w);
   EpiQK eqkv{w->qkv_b, b.q, b.k, b.v, M, C, T, Tp, heads};
   if ((rc = run_gemm(b.h, wqkv, M, 3 * C, C, eqkv, stream))) return rc;
-  if (Tp > T) {
-    const int n = B * heads * (Tp - T) * (HD * 4) / 16;
-    hipLaunchKernelGGL(zero_v_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b.v, B * heads, T, Tp);
-  }
   hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.v,
                      b.o, T, Tp, heads, 1.0f / sqrtf((float)HD));
   EpiResidual ep{w->proj_b, x_in, x_out, M, C};

@@ -159,7 +159,12 @@ def main(argv=None):
     print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         torch.cuda.set_device(device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
+        probe = torch.ones(1, device=device)             # RCCL smoke before any work: a 1-element all-reduce
+        dist.all_reduce(probe)
+        if int(probe.item()) != dist.get_world_size():
+            raise RuntimeError("RCCL all-reduce smoke failed: %r" % probe.item())
     modes = ["unsupervised", "supervised"] if args.supervised == "both" else [args.supervised]
     backbone = patchcore.backbones.load(args.backbone_names[0].split(".seed-")[0])   # once, not once per category
     results = {}

@@ -18,18 +18,21 @@ Unsupervised weights: w_i[p] = mean_{j != i} min_q |Z_i[p] - Z_j[q]|.  d(i,j) bl
 transposed, so every UNORDERED pair of image blocks is multiplied once and reduced in both directions
 (half the MFMA work of "my queries x all keys").  Two schedules:
 
-  "slices" (N^2 * P * 4 bytes <= budget, every MVTec category): the packed shards are all-gathered
-      (one RCCL all-gather of hl32 + norms: N = 167 -> 2.1 GB), each rank runs slice r/G of the folded
-      upper-triangle tile space of the whole N*P x N*P problem into its own [N, N*P] matrix of minima,
-      one MIN all-reduce (N = 167: 87 MB) completes it.  Perfectly balanced at any N.
-  "ring" (anything larger, e.g. N = 10 000): nothing is gathered.  Rank r keeps its shard resident and
-      receives the shard of rank r+k at ring step k = 1 .. G/2 into a double buffer (the transfer of step
-      k+1 runs under the MFMA work of step k); it multiplies (its shard) x (that shard) two-way, in
-      sub-blocks of c x c images sized to the minbuf budget, and for even G the step k = G/2 block is split
-      between its two owners.  Sums for the other rank's queries go into the same [N*P] int64 accumulator;
+  "ring" (the default): nothing is gathered.  Rank r keeps its shard resident and receives the shard of rank
+      r+k for the ring steps k = 1 .. G/2 - HALF the shards, each over its own xGMI link, all posted up front
+      for an MVTec-sized category (so they travel under the local work of step 0), double-buffered for a large
+      one (N = 10 000: the transfer of step k+2 runs under the MFMA work of step k); it multiplies
+      (its shard) x (that shard) two-way, in sub-blocks of c x c images sized to the minbuf budget, and for even
+      G the step k = G/2 block is split between its two owners.  Sums for the other rank's queries go into the same [N*P] int64 accumulator;
       ONE all-reduce(SUM) of it at the end hands every rank its complete sums.  Per-GPU bytes at N = 10 000,
       G = 8, P = 784, D = 4096: Z fp32 16 GB + hl32 16 GB + 2 x 16 GB receive buffers + 2 x 1 GiB minbuf
       + 63 MB accumulator = 66 GB of 288.
+
+  "slices" (kept as an alternative; needs N^2 * P * 4 bytes of minima): the packed shards are all-gathered
+      (one RCCL all-gather of hl32 + norms: N = 167 -> 2.1 GB on every rank), each rank runs slice r/G of the
+      upper-triangle tile space of the whole N*P x N*P problem into its own [N, N*P] matrix of minima, one MIN
+      all-reduce (N = 167: 87 MB) completes it.  Perfectly balanced, but it moves G - 1 shards to every rank
+      before any MFMA work can start.
 
 The sum over key images is kept in 64-bit fixed point (csrc/alpha.hip), so both schedules, any rank count
 and any block size give bit-identical w for the same Z.  On one GPU the ring schedule degenerates to
@@ -51,6 +54,7 @@ import torch.distributed as dist
 
 
 MINBUF_BYTES = 1 << 30        # largest matrix of minima one launch may fill (x2 for a two-way block)
+REMOTE_BYTES = 8 << 30        # receive buffers of the ring: all steps in flight when they fit, else two buffers
 MEAN, MIN = 0, 1              # acnative.REDUCE_MEAN_OTHERS / REDUCE_MIN_ALL
 NO_SELF = -(1 << 62)
 
@@ -204,28 +208,35 @@ def select_bank(n_train, n_test, train_ratio, seed=0):
 # ------------------------------------------------------------------ the ring of packed shards
 class _Ring:
     """Shard exchange of the ring schedule: at step k every rank sends its own packed shard to rank - k and
-    receives the shard of rank + k into one of two buffers.  prefetch(k) posts the transfer, get(k) waits
-    for it (the wait is a stream dependency under RCCL) - posting step k+1 before computing step k overlaps
-    the transfer with the MFMA work.  Under a host backend (gloo: the CPU tests, and the tests that run two
-    ranks on ONE GPU, which RCCL refuses) device tensors are staged through host memory."""
+    receives the shard of rank + k.  prefetch(k) posts the transfer, get(k) waits for it (the wait is a stream
+    dependency under RCCL).  `depth` receive buffers: a small category posts EVERY step's transfer up front, so the
+    shards travel over different xGMI links at the same time and under the local work of step 0; a large one
+    (N = 10 000: 16 GB per shard) keeps two buffers and fetches step k + 2 when step k's buffer is free.
+    Under a host backend (gloo: the CPU tests, and the tests that run several ranks on ONE GPU, which RCCL
+    refuses) device tensors are staged through host memory."""
 
-    def __init__(self, ops, local, sizes, rank, world, group):
+    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES):
         self.ops, self.local, self.sizes, self.rank, self.world, self.group = ops, local, sizes, rank, world, group
         self.cap = max(sizes) if sizes else 0
-        self.bufs = [None, None]
+        self.last = last_step
+        per_buffer = max(1, sum(t[:1].numel() * t.element_size() for t in local.tensors()) * local.P * self.cap)
+        self.depth = max(2, min(max(last_step, 1), remote_bytes // per_buffer))
+        self.bufs = [None] * self.depth
         self.pending = {}
         self.stage = world > 1 and dist.get_backend(group) != "nccl" and local.tensors()[0].is_cuda
         self._host_local = None
+        for k in range(1, min(self.depth, last_step) + 1):
+            self.prefetch(k)
 
     def _peer(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def prefetch(self, k):
-        if k in self.pending or k <= 0 or k >= self.world:
+        if k in self.pending or k <= 0 or k > self.last:
             return
         src, dst = (self.rank + k) % self.world, (self.rank - k) % self.world
         n_src = self.sizes[src]
-        slot = k & 1
+        slot = k % self.depth
         if self.bufs[slot] is None and n_src:
             self.bufs[slot] = self.ops.empty_packed(self.cap, self.local)
         recv = self.bufs[slot].slice(0, n_src) if n_src else None
@@ -243,6 +254,8 @@ class _Ring:
         self.pending[k] = (works, recv, host_recv)
 
     def get(self, k):
+        """The shard of rank + k (None when that shard is empty).  Also posts the transfer that may now reuse the
+        buffer of step k - 1 (whose kernels are already queued on the stream)."""
         self.prefetch(k)
         works, recv, host_recv = self.pending.pop(k)
         for w in works:
@@ -250,6 +263,7 @@ class _Ring:
         if host_recv is not None:
             for d, h in zip(recv.tensors() if recv is not None else [], host_recv):
                 d.copy_(h)
+        self.prefetch(k - 1 + self.depth)
         return recv
 
 
@@ -257,14 +271,15 @@ def _slice_global(pk, base, rng):
     return pk.slice(rng[0] - base, rng[1] - base)
 
 
-def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto"):
+def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto",
+                               remote_bytes=REMOTE_BYTES):
     """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard)."""
     n = bounds[-1][1]
     lo, hi = bounds[rank]
     P = pk_loc.P
     counts = [b - a for a, b in bounds]
     if schedule == "auto":
-        schedule = "slices" if (world > 1 and n * n * P * 4 <= budget) else "ring"
+        schedule = "ring"
     if schedule == "slices":
         rows = [c * P for c in counts]
         hl = all_gather_rows(pk_loc.hl, rows, group)
@@ -285,18 +300,15 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
     shift = ops.fixed_shift(m, n)
     acc = ops.new_acc(n * P, MEAN, device)                 # sums for EVERY image: remote queries' parts too
     c = block_images(P, budget)
-    ring = _Ring(ops, pk_loc, counts, rank, world, group)
+    ring = _Ring(ops, pk_loc, counts, rank, world, group, last_step=world // 2, remote_bytes=remote_bytes)
     by_step = {}
     for item in unsup_schedule(bounds, rank, c):
         by_step.setdefault(item[1], []).append(item)
-    ring.prefetch(1)
     for step in range(0, world // 2 + 1):
         remote, rbase = None, 0
         if step > 0:                                       # every rank takes part in every exchange, work or not
             remote = ring.get(step)
             rbase = bounds[(rank + step) % world][0]
-            if step + 1 <= world // 2:
-                ring.prefetch(step + 1)
         for item in by_step.get(step, []):
             if item[0] == "sym":
                 a = item[2]
@@ -317,20 +329,18 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
     return ops.pair_finalize(acc[lo * P: hi * P], P, MEAN, n - 1, shift)
 
 
-def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES):
+def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
+                             remote_bytes=REMOTE_BYTES):
     """w fp32 [n_loc, P]: min over every bank image (utils.py:230-237 for every i of the shard).  The bank
     shards go round the ring; each is multiplied one-way against the local queries, in sub-blocks."""
     P = pk_loc.P
     n_loc = pk_loc.n
     acc = ops.new_acc(n_loc * P, MIN, device)
     counts = [b - a for a, b in bank_bounds]
-    ring = _Ring(ops, pk_bank_loc, counts, rank, world, group)
-    ring.prefetch(1)
+    ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
     c = block_images(P, budget)
     for k in range(world):
         keys = pk_bank_loc if k == 0 else ring.get(k)
-        if k + 1 < world:
-            ring.prefetch(k + 1)
         if keys is None or keys.n == 0 or n_loc == 0:
             continue
         for q0, q1 in _subranges(0, n_loc, c):
@@ -344,12 +354,12 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
 
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
-                 schedule="auto", Z_loc=None):
+                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
-    budget / schedule: memory budget of one matrix of minima and the unsupervised schedule ("auto", "slices",
-    "ring") - results do not depend on either.
+    budget / schedule / remote_bytes: memory budget of one matrix of minima, the unsupervised schedule ("auto" =
+    "ring", or "slices") and the memory the ring may spend on receive buffers - results do not depend on any.
     Z_loc: the rank's embeddings from an earlier call on the same images (out["Z_loc"]): Z does not depend on
     the mode, so a run over several modes embeds the test set once (the reference re-embeds per mode and per tau,
     examples/main.py:346-366).
@@ -382,10 +392,12 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         bb = shard_bounds(len(sel), world)
         blo, bhi = bb[rank]
         bank_loc = ops.embed(train_images[sel[blo:bhi]])
-        w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget)
+        w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget,
+                                         remote_bytes)
         del bank_loc
     elif supervised == "unsupervised":
-        w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule)
+        w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule,
+                                           remote_bytes)
     else:                                                              # "average" (main.py:290-291)
         w_loc = None
     mark("pair_min_dist", t0)

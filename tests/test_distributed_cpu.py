@@ -128,13 +128,13 @@ def _inputs(n=7, n_train=9):
     return torch.randn(n, 3, 16, 16, generator=g), torch.randn(n_train, 3, 16, 16, generator=g)
 
 
-def _worker(rank, world, init_file, mode, out_dir, schedule="auto", budget=1 << 30):
+def _worker(rank, world, init_file, mode, out_dir, schedule="auto", budget=1 << 30, remote_bytes=8 << 30):
     sys.path[:0] = [ROOT, MODELS]
     from patchcore.pipeline import run_category
     dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
     images, train = _inputs()
     out = run_category(ToyOps(), images, mode, tau=1.0, train_images=train, train_ratio=1.0, schedule=schedule,
-                       budget=budget)
+                       budget=budget, remote_bytes=remote_bytes)
     np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].numpy())
     np.save(os.path.join(out_dir, "X_%d.npy" % rank), out["X"])
     if rank == 0:
@@ -189,6 +189,18 @@ def test_supervised_ring_with_sub_blocks():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(3, os.path.join(d, "rdzv"), "supervised", d, "auto", 2 * 2 * 12 * 4), nprocs=3, join=True)
         for r in range(3):
+            np.testing.assert_array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].numpy())
+
+
+def test_ring_with_two_receive_buffers():
+    """remote_bytes = 1 forces the double-buffered ring (what N = 10 000 runs): with 4 ranks the bank shards of the
+    supervised mode need 3 steps through 2 buffers, so a buffer is refilled while the run is in flight."""
+    from patchcore.pipeline import run_category
+    images, train = _inputs()
+    ref = run_category(ToyOps(), images, "supervised", tau=1.0, train_images=train, train_ratio=1.0)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(4, os.path.join(d, "rdzv"), "supervised", d, "auto", 1 << 30, 1), nprocs=4, join=True)
+        for r in range(4):
             np.testing.assert_array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].numpy())
 
 

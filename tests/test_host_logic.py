@@ -270,3 +270,27 @@ def test_shims_construct_and_refuse_detection_calls():
     pre = common.Preprocessing([785, 785], 2048)
     assert pre.output_dim == 2048 and len(pre.preprocessing_modules) == 2
     assert common.Aggregator(target_dim=4096).target_dim == 4096
+
+
+def test_bench_workloads_match_baseline_configs():
+    """bench.py --config: the workloads BASELINE.json / SURVEY 8d name (no GPU needed to build them)."""
+    import argparse
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("ac_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cpu = torch.device("cpu")
+
+    def build(config, **kw):
+        ns = argparse.Namespace(config=config, category=None, n=kw.get("n", 40), tau=1.0)
+        return bench.build_workload(ns, cpu)
+
+    name, items, mode = build("2")
+    assert mode == "unsupervised" and len(items) == 1 and items[0]["images"].shape == (83, 3, 224, 224) and "N=83" in name
+    name, items, mode = build("2-pill")
+    assert items[0]["category"] == "pill" and len(items[0]["labels"]) == 167
+    name, items, mode = build("5a", n=40)
+    assert mode == "average" and items[0]["images"].shape[0] == 40 and len(set(items[0]["labels"])) == 5
+    assert build("5b", n=12)[2] == "unsupervised"
+    assert bench.CONFIGS == ("2", "2-pill", "3", "4", "5a", "5b")

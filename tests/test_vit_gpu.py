@@ -141,3 +141,21 @@ def test_vit_with_dino_like_statistics(golden, dev):
         print("          vs oracle, every element: max err %.3e, max err/(atol+rtol|x|) %.3f"
               % (full.max(), (full / (ATOL + RTOL * np.abs(r))).max()))
         assert np.all(full <= ATOL + RTOL * np.abs(r))
+
+
+def test_attention_ignores_the_pad_rows_of_its_buffers(dev):
+    """T = 785 is not a multiple of the 32-key attention tile: the last tile reads 15 rows past the end of every
+    head's K and V images.  Nothing ever writes those rows, so poison the whole scratch buffer with 0xFF bytes
+    (fp16 NaNs) first: the block output must not change by a bit (padded scores are masked, padded V rows are
+    re-routed to a real row)."""
+    import acnative
+    import patchcore.vision_transformer as vits
+    torch.manual_seed(3)
+    m = vits.vit_base(patch_size=8, num_classes=0, depth=1).eval().to(dev)
+    x = torch.randn(3, 785, 768, device=dev)
+    with torch.no_grad():
+        ref = m.blocks[0](x).clone()
+        for ws in acnative._workspaces.values():
+            ws.fill_(0xFF)
+        again = m.blocks[0](x)
+    assert torch.isfinite(again).all() and torch.equal(again, ref)
