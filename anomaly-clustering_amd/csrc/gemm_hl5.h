@@ -37,13 +37,16 @@ using gemm2::lptr_t;
 using gemm2::tile_off;
 using Frag = gemm::FragT<16>;
 
-constexpr int BM = 256, BK = 32, THREADS = 512;
+constexpr int BM = 256, BK = 32;
+constexpr int threads_of(int WN) { return 4 * WN * 64; }     // waves: 4 along M x WN along N
 constexpr int HALF = 256 * 128;                 // the A half-tile: 256 rows x 128 B
 constexpr int A_SLOTS = 3, B_SLOTS = 2;
-// NT = 16-column MFMA tiles per wave: 8 -> BN = 256 (the shape described above), 4 -> BN = 128 (64x64 per
-// wave; leaves room for the second accumulator of the two-level sum, FLUSH).
-constexpr int bn_of(int NT) { return NT * 32; }
-constexpr int lds_bytes(int NT) { return A_SLOTS * HALF + B_SLOTS * bn_of(NT) * 128; }   // 160 / 128 KB
+// NT = 16-column MFMA tiles per wave, WN = waves along N (4 waves along M always):
+//   NT 8, WN 2 -> 256x256, 8 waves, 2 per SIMD (the shape described above)
+//   NT 4, WN 2 -> 256x128, 64x64 per wave (room for the second accumulator of the two-level sum, FLUSH)
+//   NT 4, WN 3 -> 256x192, TWELVE waves, 3 per SIMD at <= 168 registers: a third MFMA-issuing wave per SIMD
+constexpr int bn_of(int NT, int WN = 2) { return NT * 16 * WN; }
+constexpr int lds_bytes(int NT, int WN = 2) { return A_SLOTS * HALF + B_SLOTS * bn_of(NT, WN) * 128; }   // 160 / 128 / 144 KB
 constexpr int FLUSH_STAGES = 16;
 
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE5=1 no DMA in the k loop, 2 no fragment
@@ -81,8 +84,8 @@ __device__ inline bool tile_of_square(int id, int tiles_m, int tiles_n, int grou
   return true;
 }
 
-template <class Epi, int NT, bool FLUSH>
-__global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+template <class Epi, int NT, bool FLUSH, int WN = 2>
+__global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
                                                      int id_lo, int id_hi, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -90,17 +93,19 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   uint8_t* const Bring = smem + A_SLOTS * HALF;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave - wm * WN;
   constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
+  static_assert(WN == 2 || !EpiTraits<Epi>::kSymmetric, "symmetric epilogues run on the 2-wave-wide kernels");
   const int nk = K / BK;
   const size_t ld = (size_t)K * 4;
 
   int tm = 0, tn = 0;
   const int id = id_lo + blockIdx.x;
-  constexpr int BN = bn_of(NT), HALF_B = BN * 128, NB = BN / 32;   // NB: B instructions per loader wave
+  constexpr int BN = bn_of(NT, WN), HALF_B = BN * 128, NB = BN / 32;   // NB: B instructions per loader wave
   if (id >= id_hi) return;
   if constexpr (NT == 8) { if (!tile_of_square(id, tiles_m, tiles_n, group_m, epi, tm, tn)) return; }
-  else { if (!gemm2::tile_of(id, tiles_m, tiles_n, group_m, M, N, epi, tm, tn)) return; }   // block-uniform
+  else if constexpr (WN == 2) { if (!gemm2::tile_of(id, tiles_m, tiles_n, group_m, M, N, epi, tm, tn)) return; }
+  else gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);                                  // block-uniform
   const int m0 = tm * BM, n0 = tn * BN;
 
   // DMA map: a half-tile is 32 wave-instructions of 1 KB (8 rows each).  Only waves 0-3 issue them
@@ -161,15 +166,10 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   dmaB(0, 0);
   if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
   if (nk > 2) dmaA(2, 2);
-  if constexpr (NT == 8) {                       // leave A(1) B(1) A(2) = 8 + NB + 8 (or 8 + NB) in flight
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  // leave A(1) B(1) A(2) = 8 + NB + 8 (or A(1) B(1) = 8 + NB) in flight
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 + NB) : "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NB) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
   half8 bh[NT], bl[NT];
 #pragma unroll
@@ -310,30 +310,35 @@ __global__ __launch_bounds__(THREADS, 1) void kernel(const uint8_t* __restrict__
   }
 }
 
-template <class Epi, int NT = 8, bool FLUSH = false>
+template <class Epi, int NT = 8, bool FLUSH = false, int WN = 2>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 4, int part = 0, int nparts = 1) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl5: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl5: bad part %d/%d", part, nparts);
-  constexpr int BN = bn_of(NT), LDS_BYTES = lds_bytes(NT);
+  constexpr int BN = bn_of(NT, WN), LDS_BYTES = lds_bytes(NT, WN), THREADS = threads_of(WN);
   int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  long long total = (long long)tiles_m * tiles_n;
   if constexpr (EpiTraits<Epi>::kSymmetric) {
-    if (epi.symmetric) {                           // folded upper triangle (tile_of_square / gemm2::tile_of)
+    if (epi.symmetric) {                           // upper triangle (tile_of_square / gemm2::tile_of)
       if (M != N) return ac_fail(AC_EINVAL, "gemm_hl5: symmetric epilogue needs M == N");
-      const int Tm = tiles_m, Tn = tiles_n;
-      tiles_m = (Tm + 1) / 2;
-      tiles_n = NT == 8 ? Tm + 1 : 2 * Tn - 2 * Tm + 2;
+      if (NT == 8) {                               // folded into a ceil(T/2) x (T+1) rectangle
+        const int Tm = tiles_m;
+        tiles_m = (Tm + 1) / 2;
+        tiles_n = Tm + 1;
+        total = (long long)tiles_m * tiles_n;
+      } else {
+        total = gemm2::tri_rows_before(tiles_m, tiles_n);
+      }
     }
   }
-  long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl5: grid too large");
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
-  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH>), LDS_BYTES, &attr_done)) return rc;
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH, WN>), LDS_BYTES, &attr_done)) return rc;
   long long lo = (total * part / nparts) & ~7LL;
   long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
-  hipLaunchKernelGGL((kernel<Epi, NT, FLUSH>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
+  hipLaunchKernelGGL((kernel<Epi, NT, FLUSH, WN>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
                      group_m, (int)lo, (int)hi, epi);
   return ac_check_launch("gemm_hl5");

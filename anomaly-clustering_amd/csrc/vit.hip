@@ -30,6 +30,9 @@ static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi
   if (policy == 103) return gemm3::launch<Epi>(A, B, M, N, K, epi, stream);
   if (policy == 104) return gemm4::launch<Epi, 0>(A, B, M, N, K, epi, stream);
   if (policy == 105) return gemm4::launch<Epi, 1>(A, B, M, N, K, epi, stream);
+  // 256x192 on TWELVE waves (3 per SIMD, 158 registers): the "third MFMA-issuing wave per SIMD" experiment of
+  // round 2 - bit-identical, 2.5 % SLOWER than the 8-wave 256x256 kernel on a ViT block at 83 images
+  if (policy == 107) return gemm5::launch<Epi, 4, false, 3>(A, B, M, N, K, epi, stream);
 #endif
   const long long tiles5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
   const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && 2 * tiles5 > ac_device_cus());
