@@ -1,0 +1,42 @@
+"""GPU: bench.py prints ONE JSON line with the contract's fields, for the workloads that can be shrunk to seconds
+(config 5a / 5b at a tiny --n with a tiny minbuf budget, so that the sub-blocked schedule is what runs).  The
+full-size default run is the driver's job; this guards the plumbing around it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_config_5b_small():
+    d = _bench("--config", "5b", "--n", "40", "--budget-mb", "1", "--no-cpu-baseline", "--steps", "1")
+    assert REQUIRED <= set(d) and d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    assert d["config"]["images_per_step"] == 40 and "N=40" in d["config"]["workload"]
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and 0 < roof["frac"] < 2 / 3
+    assert roof["launches_per_step"] > 1                     # 1 MiB budget: 18-image blocks -> several launches
+    # N(N-1) ordered pairs x 2 P^2 D per step, whatever the blocking
+    total = roof["algorithmic_flop_per_launch"] * roof["launches"]
+    assert abs(total - 40 * 39 * 2.0 * 784 * 784 * 4096) / total < 1e-9
+    assert d["ward_metrics_ms"] > 0 and 0 <= d["clustering"]["NMI"] <= 1
+
+
+def test_bench_config_5a_small():
+    d = _bench("--config", "5a", "--n", "24", "--no-cpu-baseline", "--steps", "1")
+    assert REQUIRED <= set(d) and d["roofline"]["kernel"].startswith("ViT forward") and d["roofline"]["frac"] < 1 / 3
