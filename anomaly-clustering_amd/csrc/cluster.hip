@@ -21,13 +21,17 @@
 #include <limits.h>
 
 // ------------------------------------------------------------------ condensed -> square
-__global__ void condensed_to_square_kernel(const double* __restrict__ c, int n, double* __restrict__ D) {
+// Also validates the input: a NaN or an infinite distance (scipy raises ValueError on those) sets *bad, and the
+// kernels after this one return at once - the chain would otherwise walk off its arrays.
+__global__ void condensed_to_square_kernel(const double* __restrict__ c, int n, double* __restrict__ D, int* __restrict__ bad) {
   const size_t total = (size_t)n * n;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
     if (i == j) { D[e] = 0.0; continue; }
     const int a = i < j ? i : j, b = i < j ? j : i;
-    D[e] = c[(size_t)a * n - (size_t)a * (a + 1) / 2 + (b - a - 1)];
+    const double v = c[(size_t)a * n - (size_t)a * (a + 1) / 2 + (b - a - 1)];
+    if (!(fabs(v) <= 1.7976931348623157e308)) *bad = 1;      // NaN or +-inf
+    D[e] = v;
   }
 }
 
@@ -37,7 +41,9 @@ __device__ inline void argmin_take(double& d, int& i, double d2, int i2) {
 
 // ------------------------------------------------------------------ nearest-neighbour chain (one workgroup)
 __global__ __launch_bounds__(1024) void ward_nn_chain_kernel(double* __restrict__ D, int n, int* __restrict__ size,
-                                                             int* __restrict__ chain, double* __restrict__ Zraw) {
+                                                             int* __restrict__ chain, double* __restrict__ Zraw,
+                                                             const int* __restrict__ bad) {
+  if (*bad) return;                                 // block-uniform
   __shared__ double red_d[16];
   __shared__ int red_i[16];
   __shared__ int sh_x, sh_prev, sh_y, sh_len, sh_first, sh_done, sh_nx, sh_ny;
@@ -131,9 +137,9 @@ __global__ __launch_bounds__(1024) void ward_nn_chain_kernel(double* __restrict_
 
 // ------------------------------------------------------------------ stable sort by distance + relabel
 // rank[i] = #{j : d_j < d_i or (d_j == d_i and j < i)}: the position numpy's stable argsort gives merge i.
-__global__ void rank_sort_kernel(const double* __restrict__ Zraw, int m, double* __restrict__ Zs) {
+__global__ void rank_sort_kernel(const double* __restrict__ Zraw, int m, double* __restrict__ Zs, const int* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+  if (i >= m || *bad) return;
   const double di = Zraw[(size_t)i * 4 + 2];
   int r = 0;
   for (int j = 0; j < m; ++j) {
@@ -145,8 +151,9 @@ __global__ void rank_sort_kernel(const double* __restrict__ Zraw, int m, double*
 }
 
 // scipy's label(): walk the sorted merges with a union-find whose roots carry the new cluster ids n, n+1, ...
-__global__ void relabel_kernel(double* __restrict__ Z, int n, int* __restrict__ parent, int* __restrict__ csize) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void relabel_kernel(double* __restrict__ Z, int n, int* __restrict__ parent, int* __restrict__ csize,
+                               const int* __restrict__ bad) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || *bad) return;
   for (int i = 0; i < 2 * n - 1; ++i) { parent[i] = i; csize[i] = 1; }
   int next_label = n;
   auto find = [&](int x) {
@@ -175,11 +182,12 @@ extern "C" size_t ac_ward_workspace_bytes(int64_t n) {
          align_up((size_t)(2 * n - 1) * 4, 256) * 2 + 256;
 }
 
-extern "C" int ac_ward_linkage(const double* condensed, int64_t n, double* Z, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int ac_ward_linkage(const double* condensed, int64_t n, double* Z, int32_t* bad_input_flag, void* ws, size_t ws_bytes,
+                               void* stream_) {
   hipStream_t stream = as_stream(stream_);
   AC_REQUIRE(n >= 0 && n <= 46000, "ac_ward_linkage: n=%lld out of range (0..46000)", (long long)n);
   if (n < 2) return AC_OK;
-  AC_REQUIRE(condensed && Z && ws, "ac_ward_linkage: null pointer");
+  AC_REQUIRE(condensed && Z && ws && bad_input_flag, "ac_ward_linkage: null pointer");
   if (ws_bytes < ac_ward_workspace_bytes(n)) return ac_fail(AC_EWORKSPACE, "ac_ward_linkage: workspace too small");
   Arena ar(ws, ws_bytes);
   double* D = ar.take<double>((size_t)n * n);
@@ -190,12 +198,13 @@ extern "C" int ac_ward_linkage(const double* condensed, int64_t n, double* Z, vo
   int* csize = ar.take<int>((size_t)(2 * n - 1));
   if (!ar.ok()) return ac_fail(AC_EWORKSPACE, "ac_ward_linkage: workspace carve failed");
   const size_t total = (size_t)n * n;
+  if (hipMemsetAsync(bad_input_flag, 0, 4, stream) != hipSuccess) return ac_fail(AC_ELAUNCH, "ac_ward_linkage: hipMemsetAsync failed");
   hipLaunchKernelGGL(condensed_to_square_kernel, dim3((unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535)),
-                     dim3(256), 0, stream, condensed, (int)n, D);
-  hipLaunchKernelGGL(ward_nn_chain_kernel, dim3(1), dim3(1024), 0, stream, D, (int)n, size, chain, Zraw);
+                     dim3(256), 0, stream, condensed, (int)n, D, bad_input_flag);
+  hipLaunchKernelGGL(ward_nn_chain_kernel, dim3(1), dim3(1024), 0, stream, D, (int)n, size, chain, Zraw, bad_input_flag);
   const int m = (int)n - 1;
-  hipLaunchKernelGGL(rank_sort_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, Zraw, m, Z);
-  hipLaunchKernelGGL(relabel_kernel, dim3(1), dim3(64), 0, stream, Z, (int)n, parent, csize);
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, Zraw, m, Z, bad_input_flag);
+  hipLaunchKernelGGL(relabel_kernel, dim3(1), dim3(64), 0, stream, Z, (int)n, parent, csize, bad_input_flag);
   return ac_check_launch("ac_ward_linkage");
 }
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   };
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
 
-  // first tile of this workgroup (skip holes of the folded grid)
+  // first tile of this workgroup
   int id = id_lo + blockIdx.x;
   while (id < id_hi && !setup(id)) id += gridDim.x;
   if (id >= id_hi) return;

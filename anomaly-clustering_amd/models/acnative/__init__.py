@@ -58,7 +58,7 @@ SIGNATURES = {
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
     "ac_ward_workspace_bytes": (_sz, [_i64]),
-    "ac_ward_linkage": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "ac_ward_linkage": (_i, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "ac_cluster_scores": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
@@ -539,7 +539,10 @@ def ward_linkage(condensed, n):
         return Z
     nbytes = lib().ac_ward_workspace_bytes(n)
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=condensed.device)      # ~8 n^2 bytes: not kept around
-    _check(lib().ac_ward_linkage(p, n, Z.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    bad = torch.empty(1, dtype=torch.int32, device=condensed.device)
+    _check(lib().ac_ward_linkage(p, n, Z.data_ptr(), bad.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    if int(bad.item()):
+        raise ValueError("The condensed distance matrix must contain only finite values.")     # scipy's message
     return Z
 
 

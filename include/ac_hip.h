@@ -219,9 +219,12 @@ int ac_pdist(const float* X, int64_t N, int D, double* out, void* stream);
  * scipy.cluster.hierarchy.linkage(y, method="ward") as reached from examples/test.py:193-195 through sklearn's
  * AgglomerativeClustering -> ward_tree.  Z: float64 [n-1, 4] = (cluster a, cluster b, distance, size), rows
  * sorted by distance (stable), ids relabelled as scipy does - bit-identical to scipy's Z on the same input.
- * `condensed` is not modified.  n <= 46000; workspace ~ 8 n^2 bytes. */
+ * `condensed` is not modified.  n <= 46000; workspace ~ 8 n^2 bytes.  bad_input_flag: int32 [1] (device), set to 1
+ * when a distance is NaN or infinite (scipy raises ValueError there); Z is then left unwritten - the caller checks
+ * the flag after synchronising. */
 size_t ac_ward_workspace_bytes(int64_t n);
-int ac_ward_linkage(const double* condensed, int64_t n, double* Z, void* ws, size_t ws_bytes, void* stream);
+int ac_ward_linkage(const double* condensed, int64_t n, double* Z, int32_t* bad_input_flag, void* ws, size_t ws_bytes,
+                    void* stream);
 
 /* Contingency matrix of two integer labelings (values in [0, k_true) / [0, k_pred)) and, from it, sklearn's
  * normalized_mutual_info_score and adjusted_rand_score (examples/test.py:218-219).

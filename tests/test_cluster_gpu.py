@@ -49,6 +49,19 @@ def test_linkage_large_and_degenerate(dev):
         _check_linkage(rng.normal(size=(n, 4)), dev)
 
 
+def test_linkage_rejects_non_finite_distances(dev):
+    """scipy raises ValueError on NaN / inf distances; the device chain must not walk off its arrays on them."""
+    import acnative
+    d = torch.ones(10, dtype=torch.float64, device=dev)               # n = 5
+    for poison in (float("nan"), float("inf")):
+        bad = d.clone()
+        bad[3] = poison
+        with pytest.raises(ValueError, match="finite"):
+            acnative.ward_linkage(bad, 5)
+    assert acnative.ward_linkage(d, 5).shape == (4, 4)
+    assert acnative.ward_linkage(torch.empty(0, dtype=torch.float64, device=dev), 1).shape == (0, 4)
+
+
 def test_scores_match_sklearn(dev):
     import acnative
     from sklearn import metrics

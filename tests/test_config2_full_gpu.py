@@ -3,7 +3,7 @@ through all 12 ViT blocks, aggregation and the alpha engine - checked through pr
 oracle run at that size:
 
   * alpha rows sum to 1 (fp64 softmax rounded to fp32: |sum - 1| <= 1e-5), finite, positive;
-  * the symmetric folded-grid path (65 072 / 130 928 patch rows - far beyond the 3 920 rows of the small parity
+  * the symmetric triangle-grid path (65 072 / 130 928 patch rows - far beyond the 3 920 rows of the small parity
     cases) equals the general path (distinct key buffer: full rectangle, one-way) to 1e-5 = 5 ulp of fp32 at
     w ~ 30 (the two paths form a.b and b.a, whose three split-fp16 passes accumulate in a different order;
     measured 3.8e-6 = 2 ulp);
@@ -74,7 +74,7 @@ def test_unsupervised_category_at_full_size(dev, core, category, n):
     w_sym = out["w_loc"]
     assert torch.equal(w_sym, acnative.pair_min_dist(Z, Z, acnative.REDUCE_MEAN_OTHERS))     # reproducible
     w_gen = acnative.pair_min_dist_staged(Z, Z.clone(), acnative.REDUCE_MEAN_OTHERS)
-    assert (w_sym - w_gen).abs().max().item() <= 1e-5, "symmetric folded grid vs general rectangle"
+    assert (w_sym - w_gen).abs().max().item() <= 1e-5, "symmetric triangle grid vs general rectangle"
     idx = [0, n // 2, n - 1]
     truth = _truth_rows(Z, Z, idx, 0)
     err = (w_sym[idx].double() - truth).abs().max().item()
