@@ -25,10 +25,19 @@ __global__ __launch_bounds__(256) void agg_stats_kernel(const float* __restrict_
   const size_t n = (size_t)C * HW;
   const float* base = f + (kind == AC_FEAT_TOKENS ? ((size_t)b * (HW + 1) + 1) * C : (size_t)b * n);
   double s = 0.0, ss = 0.0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    double v = base[i];
-    s += v;
-    ss += v * v;
+  if ((n & 3) == 0 && ((uintptr_t)base & 15) == 0) {           // 16-byte loads (every ViT / CNN shape on the path)
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(base);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
+      const f32x4 q = b4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const double v = q[j]; s += v; ss += v * v; }
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      double v = base[i];
+      s += v;
+      ss += v * v;
+    }
   }
   s = wave_sum(s);
   ss = wave_sum(ss);
@@ -44,14 +53,21 @@ __global__ __launch_bounds__(256) void agg_stats_kernel(const float* __restrict_
 }
 
 // one wave per image: lane c holds chunk c's partial, fixed-order butterfly
-__global__ __launch_bounds__(64) void agg_stats_finish_kernel(const double* __restrict__ partial, int chunks,
-                                                              double* __restrict__ stats /* [B][2] */) {
+// ... and turns them into the image's mean and 1/std ONCE (fp64, rounded to fp32 as LayerNorm's fp32 arithmetic
+// sees them) - the pool kernels used to redo this fp64 division + square root in every thread of every workgroup.
+__global__ __launch_bounds__(64) void agg_stats_finish_kernel(const double* __restrict__ partial, int chunks, double n,
+                                                              float eps, float* __restrict__ norm /* [B][2] */) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const double* p = partial + ((size_t)b * kStatChunks + lane) * 2;
   double s = lane < chunks ? p[0] : 0.0, ss = lane < chunks ? p[1] : 0.0;
   s = wave_sum(s);
   ss = wave_sum(ss);
-  if (lane == 0) { stats[b * 2] = s; stats[b * 2 + 1] = ss; }
+  if (lane == 0) {
+    const double mean_d = s / n;
+    const double var_d = fmax(ss / n - mean_d * mean_d, 0.0);
+    norm[b * 2] = (float)mean_d;
+    norm[b * 2 + 1] = (float)(1.0 / sqrt(var_d + (double)eps));
+  }
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs, and neighbouring patches share 6 of their 9 tokens:
@@ -64,7 +80,7 @@ __device__ inline int xcd_local_patch(int bid, int n) {
 
 struct AggLayer {
   const float* f;
-  const double* stats;   // [B][2]
+  const float* norm;     // [B][2]: mean, 1/sqrt(var + eps) of the image's C*H*W values
   int kind, C, H, W;
 };
 struct AggParams {
@@ -103,10 +119,7 @@ __global__ __launch_bounds__(256) void agg_pool_kernel(AggParams prm) {
   for (int l = 0; l < prm.n_layers; ++l) {
     const AggLayer L = prm.layer[l];
     const int HW = L.H * L.W, Lk = L.C * k2;
-    const double n = (double)L.C * HW;
-    const double mean_d = L.stats[b * 2] / n;
-    const double var_d = fmax(L.stats[b * 2 + 1] / n - mean_d * mean_d, 0.0);
-    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)prm.eps));
+    const float mean = L.norm[b * 2], rstd = L.norm[b * 2 + 1];
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     bilinear_src(y, L.H, prm.H0, y0, y1, ly0, ly1);
@@ -196,10 +209,7 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_kernel(AggParams prm) {
   for (int l = 0; l < prm.n_layers; ++l) {
     const AggLayer L = prm.layer[l];
     const int HW = L.H * L.W, Lk = L.C * K2;
-    const double n = (double)L.C * HW;
-    const double mean_d = L.stats[b * 2] / n;
-    const double var_d = fmax(L.stats[b * 2 + 1] / n - mean_d * mean_d, 0.0);
-    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)prm.eps));
+    const float mean = L.norm[b * 2], rstd = L.norm[b * 2 + 1];
     const float* img = L.f + ((size_t)b * (HW + 1) + 1) * L.C;
     for (int c4 = tid * 4; c4 < L.C; c4 += 1024) {
       f32x4 ld[K2];
@@ -247,6 +257,54 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_kernel(AggParams prm) {
   }
 }
 
+// ---- pass 2, register path for the DINO ViT shape: token maps on one grid, K = 3, 3 * pre == 8 * C per layer
+// (C = 768 -> 6912 unfolded values pooled to 2048: every 8 outputs read exactly 27 = 3 channels x 9 neighbours
+// inputs), identity final pool.  Thread t owns channels 3t..3t+2: its 27 inputs are nine 12-byte loads (one per
+// neighbour token, contiguous across the wave), all in flight at once; its 8 outputs are window sums over those registers, in the same order as the kernels
+// above (bit-identical results), written as two 16-byte stores.  One (patch, layer) per workgroup.  No LDS, no
+// barrier, no bank conflicts: what is left is the 16 KB row write per patch (HBM) and the neighbour re-reads
+// from L2.
+struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+
+__global__ __launch_bounds__(256) void agg_pool_tokens_27_8_kernel(AggParams prm) {
+  const int t = threadIdx.x;
+  const int patch = xcd_local_patch(blockIdx.x, gridDim.x), b = blockIdx.y, l = blockIdx.z;   // one layer per workgroup:
+  const int y = patch / prm.W0, x = patch - y * prm.W0;                                       // 48 registers, 8 waves per SIMD
+  if (t * 8 >= prm.pre) return;
+  const AggLayer L = prm.layer[l];
+  const int HW = L.H * L.W;
+  const float* img = L.f + ((size_t)b * (HW + 1) + 1) * L.C + 3 * t;
+  float v[27];
+#pragma unroll
+  for (int kk = 0; kk < 9; ++kk) {
+    const int yy = y + kk / 3 - 1, xx = x + kk % 3 - 1;
+    const int yc = min(max(yy, 0), L.H - 1), xc = min(max(xx, 0), L.W - 1);
+    const F3 f = *reinterpret_cast<const F3*>(img + (size_t)(yc * L.W + xc) * L.C);      // unconditional
+    v[kk] = f.a; v[9 + kk] = f.b; v[18 + kk] = f.c;                                        // e-order: c * 9 + kk
+  }
+  const float mean = L.norm[b * 2], rstd = L.norm[b * 2 + 1];
+#pragma unroll
+  for (int kk = 0; kk < 9; ++kk) {
+    const int yy = y + kk / 3 - 1, xx = x + kk % 3 - 1;
+    const bool inb = (yy >= 0 && yy < L.H && xx >= 0 && xx < L.W);          // Unfold pads with zeros AFTER the LayerNorm
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c * 9 + kk] = inb ? (v[c * 9 + kk] - mean) * rstd : 0.f;
+  }
+  float out[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int s = (q * 27) / 8, e = ((q + 1) * 27 + 7) / 8;                 // adaptive_avg_pool1d window, local
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 27; ++i)
+      if (i >= s && i < e) acc += v[i];
+    out[q] = (e - s) == 4 ? acc * 0.25f : acc / (float)(e - s);            // x / 4 == x * 0.25 exactly
+  }
+  float* o = prm.Z + ((size_t)b * prm.H0 * prm.W0 + patch) * prm.tgt + l * prm.pre + 8 * t;
+  *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
+  *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+}
+
 extern "C" size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C, const int* H, const int* W, int B,
                                                      int patchsize, int pre_dim, int tgt_dim) {
   (void)C; (void)H; (void)W; (void)patchsize; (void)pre_dim; (void)tgt_dim;
@@ -270,13 +328,13 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
   AggParams prm;
   prm.n_layers = n_layers; prm.k = patchsize; prm.pre = pre_dim; prm.tgt = tgt_dim;
   prm.H0 = H[0]; prm.W0 = W[0]; prm.eps = eps; prm.Z = Z;
-  double* stats = static_cast<double*>(ws);
-  double* partial = stats + align_up((size_t)n_layers * B * 2 * sizeof(double), 256) / sizeof(double);
+  float* norm = static_cast<float*>(ws);
+  double* partial = reinterpret_cast<double*>(static_cast<uint8_t*>(ws) + align_up((size_t)n_layers * B * 2 * sizeof(double), 256));
   int maxL = 0;
   for (int l = 0; l < n_layers; ++l) {
     AC_REQUIRE(feats[l] && C[l] > 0 && H[l] > 0 && W[l] > 0, "ac_patch_aggregate: bad layer %d", l);
     AC_REQUIRE(kind[l] == AC_FEAT_TOKENS || kind[l] == AC_FEAT_NCHW, "ac_patch_aggregate: bad kind for layer %d", l);
-    prm.layer[l] = AggLayer{feats[l], stats + (size_t)l * B * 2, kind[l], C[l], H[l], W[l]};
+    prm.layer[l] = AggLayer{feats[l], norm + (size_t)l * B * 2, kind[l], C[l], H[l], W[l]};
     maxL = maxL > C[l] * patchsize * patchsize ? maxL : C[l] * patchsize * patchsize;
     size_t n = (size_t)C[l] * H[l] * W[l];
     int chunks = (int)((n + 256 * 16 - 1) / (256 * 16));
@@ -284,7 +342,8 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
     double* part_l = partial + (size_t)l * B * kStatChunks * 2;
     hipLaunchKernelGGL(agg_stats_kernel, dim3(chunks, B), dim3(256), 0, stream, feats[l], kind[l], C[l], H[l] * W[l],
                        part_l);
-    hipLaunchKernelGGL(agg_stats_finish_kernel, dim3(B), dim3(64), 0, stream, part_l, chunks, stats + (size_t)l * B * 2);
+    hipLaunchKernelGGL(agg_stats_finish_kernel, dim3(B), dim3(64), 0, stream, part_l, chunks, (double)n, eps,
+                       norm + (size_t)l * B * 2);
   }
   AC_REQUIRE((long long)(pre_dim + 1) * maxL < (1LL << 31) && (long long)(tgt_dim + 1) * n_layers * pre_dim < (1LL << 31),
              "ac_patch_aggregate: pooling index arithmetic would overflow 32 bits");
@@ -294,6 +353,14 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
   for (int l = 0; l < n_layers; ++l) {
     fast = fast && kind[l] == AC_FEAT_TOKENS && H[l] == H[0] && W[l] == W[0] && C[l] % 4 == 0;
     maxC = maxC > C[l] ? maxC : C[l];
+  }
+  // register path: the DINO ViT shape (see agg_pool_tokens_27_8_kernel)
+  bool reg27 = fast && patchsize == 3 && n_layers * pre_dim == tgt_dim && pre_dim % 8 == 0 && pre_dim / 8 <= 256 &&
+               tgt_dim % 4 == 0;
+  for (int l = 0; l < n_layers && reg27; ++l) reg27 = (3LL * pre_dim == 8LL * C[l]) && C[l] % 3 == 0;
+  if (reg27) {
+    hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
+    return ac_check_launch("ac_patch_aggregate(tokens, registers)");
   }
   if (fast) {
     const bool identity = (n_layers * pre_dim == tgt_dim);

@@ -86,3 +86,23 @@ def test_adaptive_windows_match_survey():
     assert (widths == 4).sum() == 1536 and (widths == 5).sum() == 512
     s2, e2 = adaptive_windows(4096, 4096)
     assert np.array_equal(e2 - s2, np.ones(4096, dtype=np.int64))          # identity at 2*2048 -> 4096
+
+
+def test_register_path_equals_generic_path(dev):
+    """The DINO ViT shape (token maps, C = 768, 3x3, 6912 -> 2048 per layer, identity final pool) runs the register
+    kernel (no LDS); the same feature maps handed over as NCHW run the generic LDS kernel.  Same standardisation,
+    same pooling windows summed in the same order: equal up to the last bit of the per-image statistics (their fp64
+    partial sums are grouped by memory layout)."""
+    import acnative
+    B = 3
+    toks = [torch.from_numpy(gaussish_tensor((B, 785, 768), salt=81 + l, scale=2.0 + l)).to(dev) + 0.25 * l for l in range(2)]
+    Z_reg, grids = acnative.patch_aggregate(toks, 3, 2048, 4096)
+    nchw = [t[:, 1:].reshape(B, 28, 28, 768).permute(0, 3, 1, 2).contiguous() for t in toks]
+    Z_gen, _ = acnative.patch_aggregate(nchw, 3, 2048, 4096)
+    assert grids == [[28, 28], [28, 28]] and Z_reg.shape == (B * 784, 4096)
+    a, b = Z_reg.cpu().numpy(), Z_gen.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-6)
+    assert (a == b).mean() > 0.9
+    # one layer, and a shape that must NOT take the register path (pre = 1024): still the LDS kernels' answer
+    Z1, _ = acnative.patch_aggregate(toks[:1], 3, 2048, 2048)
+    np.testing.assert_allclose(Z1.cpu().numpy(), a[:, :2048], rtol=2e-6, atol=1e-6)
