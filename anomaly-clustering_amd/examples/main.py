@@ -38,7 +38,7 @@ import patchcore.sampler  # noqa: E402
 import patchcore.datasets.mvtec as mvtec  # noqa: E402
 import patchcore.datasets.synthetic as synthetic  # noqa: E402
 from patchcore.patchcore import AnomalyClusteringCore  # noqa: E402
-from patchcore.pipeline import HipOps, run_category  # noqa: E402
+from patchcore.pipeline import HipOps, run_category, select_bank, shard_bounds  # noqa: E402
 
 device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu")
 
@@ -102,13 +102,23 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
     # The reference walks the test set twice with batch size 1 (main.py:254-262, :266).
     # `cache` (a dict the caller keeps per category): the loaded test set and its embeddings Z are the same for
     # every mode, so `--supervised both` decodes and embeds the test images once.
+    # Launched under torchrun, a rank decodes only the files of its own image shard (records of all).
     cache = {} if cache is None else cache
+    multi = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
     if "images" not in cache:
-        cache["images"], cache["info"] = test_dataset.load_category(device)
+        cache["images"], cache["info"] = test_dataset.load_category(
+            device, only=shard_bounds(len(test_dataset), world)[rank] if world > 1 else None)
     images, info = cache["images"], cache["info"]
     train_images = None
     if supervised == "supervised":
-        train_images, _ = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset).load_category(device)
+        train_ds = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset)
+        only = None
+        if world > 1:                               # the bank images this rank embeds: its slice of the seeded selection
+            sel = select_bank(len(train_ds), len(test_dataset), train_ratio, 0)
+            blo, bhi = shard_bounds(len(sel), world)[rank]
+            only = set(int(i) for i in sel[blo:bhi])
+        train_images, _ = train_ds.load_category(device, only=only)
     out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
                        train_images=train_images, train_ratio=train_ratio, want_pdist=False, Z_loc=cache.get("Z_loc"))
     cache["Z_loc"] = out["Z_loc"]

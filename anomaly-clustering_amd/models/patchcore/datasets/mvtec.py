@@ -96,13 +96,15 @@ class MVTecDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data_to_iterate)
 
-    def load_category(self, device, batch_size=64):
+    def load_category(self, device, batch_size=64, only=None):
         """ONE pass over the split for the MI355X pipeline (the reference walks the dataset twice with batch size 1:
         once for the per-image records, examples/main.py:254-262, once to embed, :266): every file is decoded once
         on the host (PIL), the uint8 pixels of equally sized images go to the device in batches and the whole
         transform chain runs there (acnative.preprocess_images: bit-identical to transform_img).
         Returns (images fp32 [N, 3, S, S] on `device`, info) with info[i] = the item dict without pixels, in the
-        form DataLoader(batch_size=1) collates it (what examples/test.py reads)."""
+        form DataLoader(batch_size=1) collates it (what examples/test.py reads).
+        only = (lo, hi) or a set of indices: decode and transform only those images - a rank of a multi-GPU run
+        needs the pixels of its own shard (the other rows of `images` stay unwritten) but the records of all."""
         import PIL.Image
         import acnative
         n = len(self.data_to_iterate)
@@ -123,12 +125,19 @@ class MVTecDataset(torch.utils.data.Dataset):
                 images[torch.tensor(idx, device=device)] = out
             pending.clear()
 
+        if only is None:
+            wanted = range(n)
+        elif isinstance(only, tuple):
+            wanted = range(only[0], only[1])
+        else:
+            wanted = set(int(i) for i in only)
         for i, (classname, anomaly, image_path, _mask) in enumerate(self.data_to_iterate):
-            arr = np.asarray(PIL.Image.open(image_path).convert("RGB"))
-            if shape is not None and (arr.shape != shape or len(pending) >= batch_size):
-                flush()
-            shape = arr.shape
-            pending.append((i, arr))
+            if i in wanted:
+                arr = np.asarray(PIL.Image.open(image_path).convert("RGB"))
+                if shape is not None and (arr.shape != shape or len(pending) >= batch_size):
+                    flush()
+                shape = arr.shape
+                pending.append((i, arr))
             info.append({"classname": [classname], "anomaly": [anomaly],
                          "is_anomaly": torch.tensor([int(anomaly != "good")]),
                          "image_name": ["/".join(image_path.split("/")[-4:])], "image_path": [image_path]})

@@ -92,9 +92,9 @@ class SyntheticMVTecDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.anomalies)
 
-    def load_category(self, device, batch_size=64):
+    def load_category(self, device, batch_size=64, only=None):
         """Same contract as MVTecDataset.load_category: (images on `device`, per-image records as collated by a
-        batch-size-1 DataLoader) from one pass."""
+        batch-size-1 DataLoader) from one pass (`only` is accepted and ignored: the pixels already exist)."""
         info = []
         for idx in range(len(self)):
             item = self[idx]

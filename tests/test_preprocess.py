@@ -123,3 +123,8 @@ def test_one_pass_category_loader_equals_per_item_host_path(dev, tmp_path):
         for key in ("classname", "anomaly", "image_name", "image_path"):
             assert info[i][key] == item[key]
         assert torch.equal(info[i]["is_anomaly"], item["is_anomaly"])
+    # a rank's view: only its shard (a range) / its bank images (a set) are decoded, the records are complete
+    part, info_p = ds.load_category(dev, batch_size=2, only=(3, 7))
+    assert torch.equal(part[3:7], images[3:7]) and [r["image_name"] for r in info_p] == [r["image_name"] for r in info]
+    some, _ = ds.load_category(dev, only={0, 5, 8})
+    assert all(torch.equal(some[i], images[i]) for i in (0, 5, 8))
