@@ -57,6 +57,39 @@ def test_product_refuses_cpu_tensors():
         acnative.pdist(torch.zeros(4, 8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         acnative.patch_aggregate([torch.zeros(1, 5, 8)], 3, 8, 8)
+    # round-2 entry points: input pipeline, staged alpha blocks, clustering
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        acnative.preprocess_images(torch.zeros(1, 300, 300, 3, dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        acnative.pack_images(torch.zeros(2, 8, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        acnative.ward_linkage(torch.zeros(3, dtype=torch.float64), 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        acnative.cluster_scores(torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int32), 1, 1)
+    from patchcore.clustering import cluster_metrics
+    with pytest.raises(RuntimeError, match="no CPU fallback"):                  # the whole clustering chain, host data
+        cluster_metrics(torch.zeros(6, 8).numpy(), ["a", "b", "a", "b", "a", "b"], device=torch.device("cpu"))
+
+
+def test_argument_validation_of_the_round2_entry_points():
+    """Shape / range checks that must fail BEFORE anything is launched (no GPU here)."""
+    import acnative
+    lib = acnative.lib()
+    m3 = (ctypes.c_float * 3)(0.5, 0.5, 0.5)
+    assert lib.ac_preprocess_images(ctypes.c_void_p(16), 1, 50, 400, 100, 224, m3, m3, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                    1 << 20, None) == 1 and b"smaller than the crop" in lib.ac_last_error()
+    assert lib.ac_preprocess_workspace_bytes(4, 900, 900, 256, 224) > 4 * 224 * 224 * 3
+    assert lib.ac_ward_linkage(ctypes.c_void_p(16), 50000, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 1 << 30,
+                               None) == 1 and b"out of range" in lib.ac_last_error()
+    assert lib.ac_ward_linkage(ctypes.c_void_p(16), 100, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 64,
+                               None) == 2
+    assert lib.ac_ward_workspace_bytes(10000) >= 8 * 10000 * 10000
+    assert lib.ac_pair_accumulate(ctypes.c_void_p(16), 4, 2, 8, 4, 0, 0, None, ctypes.c_void_p(16), None) == 1   # ld < ncols
+    assert lib.ac_pair_accumulate(ctypes.c_void_p(16), 4, 8, 8, 4, 0, 0, None, ctypes.c_void_p(16), None) == 1   # mean needs shift
+    assert lib.ac_pair_min_sq_packed(ctypes.c_void_p(16), ctypes.c_void_p(16), 2, ctypes.c_void_p(16), ctypes.c_void_p(16), 2, 8, 64,
+                                     ctypes.c_void_p(16), ctypes.c_void_p(32), 0, 1, None) == 1                   # symmetric + minbuf_t
+    assert b"symmetric case" in lib.ac_last_error()
+    assert lib.ac_set_gemm_policy(77) == 1 and lib.ac_set_gemm_policy(0) == 0
 
 
 def test_product_never_imports_the_oracle():
