@@ -46,7 +46,7 @@ def _to_tensor(img):
     arr = np.asarray(img)
     if arr.ndim == 2:
         arr = arr[:, :, None]
-    t = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1)
+    t = torch.from_numpy(np.array(arr)).permute(2, 0, 1)       # a writable copy (PIL hands out a read-only view)
     return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t.to(torch.float32)
 
 
