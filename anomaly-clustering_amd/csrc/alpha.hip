@@ -2,9 +2,8 @@
 // fp64 softmax, weighted-average embedding, condensed pdist.
 // Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
 // scipy pdist under examples/test.py:193-195.
-#include "gemm_hl2.h"
-#ifdef AC_EXPERIMENTAL
 #include "gemm_hl5.h"
+#ifdef AC_EXPERIMENTAL
 #include "experimental/gemm_hl1.h"
 #include "experimental/gemm_hl3.h"
 #include "experimental/gemm_hl4.h"
@@ -371,6 +370,213 @@ extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64
   AC_REQUIRE(!(minbuf_t && nparts != 1), "ac_pair_min_sq_packed: two-way blocks are not sliced");
   EpiPairMin epi{k_sq, q_sq, minbuf, same ? minbuf : minbuf_t, (int)(nk * P), (int)(nq * P), P, same, minbuf_t != nullptr};
   return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), part, nparts);
+}
+
+// ------------------------------------------- supervised weights: pruned exact nearest neighbour
+// w_i[p] = min over EVERY patch of the normal-image bank (utils.py:230-237) is a 1-nearest-neighbour search, and an
+// exact one does not need the exact distance of every pair:
+//   pass 1  d~2(a, b) = |a|^2 + |b|^2 - 2 ah.bh with the high halves only - ONE third of the MFMA work and half the
+//           operand bytes, on the 256x256 kernel (accuracy no longer depends on it).  |d~2 - d2| <= delta with
+//           delta = 2 (2^-10 + ...) |a| |b| (Cauchy-Schwarz on the dropped terms ah.bl + al.bh + al.bl, |lo| <= 2^-11 |x|)
+//           plus the fp32 accumulation error, which is two orders smaller.  For the true nearest neighbour b* and any
+//           other row b:  d~2(b*) <= d2(b*) + delta <= d2(b) + delta <= d~2(b) + 2 delta,  so b* survives when every
+//           row with  d~2 <= (running minimum of d~2) + slack,  slack >= 2 delta,  is kept as a candidate - whatever
+//           order the tiles run in, because the running minimum only falls.
+//   pass 2  the candidates (typically one to three per query patch) are re-measured exactly: sum_k (a_k - b_k)^2 in
+//           fp64 on the 22-bit split values (hi + lo) - no cancellation at all - and the minimum is taken.
+// A query whose candidate list overflows raises a flag and the caller falls back to the exhaustive kernel.
+struct EpiNNCand {
+  const float* key_sq;    // [M] bank rows
+  const float* qry_sq;    // [N] query rows
+  const float* slack;     // device [1]
+  unsigned* approx_min;   // [N] running min of d~2 (float bits), across launches
+  int* cand;              // [N][cap] bank-row indices (+ row_offset)
+  int* count;             // [N]
+  int M, N, cap, row_offset;
+  template <class F>
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane, bool = false) const {
+    if (m_wave >= M) return;                      // wave-uniform
+    const float sl = slack[0];
+    float ksq[F::NT][F::NR];
+#pragma unroll
+    for (int mi = 0; mi < F::NT; ++mi)
+#pragma unroll
+      for (int i = 0; i < F::NR; ++i) ksq[mi][i] = key_sq[min(m_wave + F::row(mi, i, lane), M - 1)];
+#pragma unroll
+    for (int ni = 0; ni < F::NT; ++ni) {
+      const int col = n_wave + F::col(ni, lane);
+      const int colc = min(col, N - 1);
+      const float qs = qry_sq[colc];
+      float d2[F::NT][F::NR];
+      float mn = __builtin_inff();
+#pragma unroll
+      for (int mi = 0; mi < F::NT; ++mi)
+#pragma unroll
+        for (int i = 0; i < F::NR; ++i) {
+          const bool live = m_wave + F::row(mi, i, lane) < M;
+          const float v = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
+          d2[mi][i] = live ? v : __builtin_inff();
+          mn = fminf(mn, d2[mi][i]);
+        }
+      mn = F::min_over_row_groups(mn);            // min over the wave's 64 rows, in every lane of the column
+      unsigned old = 0x7f800000u;
+      if (F::first_row_group(lane) && col < N) old = atomicMin(approx_min + col, __float_as_uint(mn));
+      old = __shfl(old, lane & (F::TW - 1), 64);  // the lane of the first row group that owns this column
+      const float thr = fminf(__uint_as_float(old), mn) + sl;
+      if (col < N) {
+#pragma unroll
+        for (int mi = 0; mi < F::NT; ++mi)
+#pragma unroll
+          for (int i = 0; i < F::NR; ++i)
+            if (d2[mi][i] <= thr) {
+              const int slot = atomicAdd(count + col, 1);
+              if (slot < cap) cand[(size_t)col * cap + slot] = row_offset + m_wave + F::row(mi, i, lane);
+            }
+      }
+    }
+  }
+};
+
+// hi plane of an hl32 image -> plain fp16 rows [rows][K] (the operand of pass 1)
+__global__ __launch_bounds__(256) void h16_from_hl32_kernel(const uint8_t* __restrict__ src, int64_t rows, int K,
+                                                            uint8_t* __restrict__ dst) {
+  const int64_t groups = (int64_t)K / 32;                         // 128-byte hl32 groups per row
+  const int64_t total = rows * groups * 4;                        // 16-byte pieces of hi halves
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t g = e >> 2;
+    const int piece = (int)(e & 3);
+    *reinterpret_cast<u32x4*>(dst + g * 64 + piece * 16) = *reinterpret_cast<const u32x4*>(src + g * 128 + piece * 16);
+  }
+}
+
+extern "C" int ac_h16_from_hl32(const void* hl32, int64_t rows, int K, void* dst_h16, void* stream) {
+  AC_REQUIRE(hl32 && dst_h16, "ac_h16_from_hl32: null pointer");
+  AC_REQUIRE(K > 0 && K % 64 == 0 && rows >= 0, "ac_h16_from_hl32: K=%d must be a positive multiple of 64", K);
+  if (rows == 0) return AC_OK;
+  const int64_t total = rows * (K / 32) * 4;
+  hipLaunchKernelGGL(h16_from_hl32_kernel, dim3((unsigned)((total + 255) / 256 < 65535 ? (total + 255) / 256 : 65535)), dim3(256),
+                     0, as_stream(stream), static_cast<const uint8_t*>(hl32), rows, K, static_cast<uint8_t*>(dst_h16));
+  return ac_check_launch("ac_h16_from_hl32");
+}
+
+__global__ void nn_slack_kernel(const float* __restrict__ max_sq_k, const float* __restrict__ max_sq_q, float* __restrict__ slack) {
+  // 2 delta, delta = 2 * (2^-10 + 2^-22) |a| |b| (dropped cross terms) + 2 * 160 * 2^-24 |a| |b| (fp32 accumulation of
+  // 128 MFMA steps, rigorous gamma bound), rounded up generously
+  const double na = sqrt((double)max_sq_k[0]), nb = sqrt((double)max_sq_q[0]);
+  // + an absolute term for values in fp16's subnormal range, whose low halves are bounded by 2^-25 instead of 2^-11 |x|
+  slack[0] = (float)(2.0 * 2.0 * (9.77e-4 + 2.0e-5) * na * nb * 1.01 + 1.0e-5 * (na + nb)) + 1e-30f;
+}
+
+extern "C" int ac_nn_slack(const float* max_sq_keys, const float* max_sq_queries, float* slack, void* stream) {
+  AC_REQUIRE(max_sq_keys && max_sq_queries && slack, "ac_nn_slack: null pointer");
+  hipLaunchKernelGGL(nn_slack_kernel, dim3(1), dim3(1), 0, as_stream(stream), max_sq_keys, max_sq_queries, slack);
+  return ac_check_launch("ac_nn_slack");
+}
+
+extern "C" int ac_nn_candidates(const void* Zk_h16, const float* k_sq, int64_t nk_rows, const void* Zq_h16, const float* q_sq,
+                                int64_t nq_rows, int D, const float* slack, uint32_t* approx_min, int32_t* cand,
+                                int32_t* cand_count, int cap, int64_t key_row_offset, void* stream) {
+  AC_REQUIRE(Zk_h16 && k_sq && Zq_h16 && q_sq && slack && approx_min && cand && cand_count, "ac_nn_candidates: null pointer");
+  AC_REQUIRE(nk_rows > 0 && nq_rows > 0 && D > 0 && D % 64 == 0 && cap > 0, "ac_nn_candidates: bad shape");
+  AC_REQUIRE(nk_rows <= 0x7fffff00LL && nq_rows <= 0x7fffff00LL && key_row_offset >= 0 &&
+             key_row_offset + nk_rows <= 0x7fffffffLL, "ac_nn_candidates: too many rows");
+  EpiNNCand epi{k_sq, q_sq, slack, approx_min, cand, cand_count, (int)nk_rows, (int)nq_rows, cap, (int)key_row_offset};
+  // plain fp16 rows: D / 2 "hl32 columns" give the right row stride (D * 2 bytes) and stage count (D / 64)
+  return gemm5::launch<EpiNNCand, 8, false, 2, true>(Zk_h16, Zq_h16, (int)nk_rows, (int)nq_rows, D / 2, epi, as_stream(stream), 6);
+}
+
+// pass 2: one wave per query row.  Lane l owns the hl32 groups l, l + 64, ... (32 columns each) of the 16 KB row;
+// the query's values stay in registers (hi + lo is exact in fp32: 22 bits) while its candidates stream by, every
+// candidate row as GPL * 8 independent 16-byte loads per lane.
+template <int GPL>
+__global__ __launch_bounds__(256) void nn_refine_kernel(const uint8_t* __restrict__ Zk, int64_t nk_rows, const uint8_t* __restrict__ Zq,
+                                                        int64_t nq_rows, int D, const int* __restrict__ cand,
+                                                        const int* __restrict__ count, int cap, int64_t key_row_offset,
+                                                        double* __restrict__ best, int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq_rows) return;                                        // wave-uniform
+  int n = count[q];
+  if (n > cap) { if (lane == 0) *overflow = 1; return; }           // the caller re-measures this query exhaustively
+  if (n == 0) return;
+  const int groups = D / 32;
+  const size_t ld = (size_t)D * 4;
+  float av[GPL][32];
+  const uint8_t* a = Zq + (size_t)q * ld;
+#pragma unroll
+  for (int u = 0; u < GPL; ++u) {
+    const int g = min(lane + 64 * u, groups - 1);
+#pragma unroll
+    for (int piece = 0; piece < 4; ++piece) {
+      const half8 h = *reinterpret_cast<const half8*>(a + (size_t)g * 128 + piece * 16);
+      const half8 l = *reinterpret_cast<const half8*>(a + (size_t)g * 128 + 64 + piece * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[u][piece * 8 + j] = (float)h[j] + (float)l[j];
+    }
+  }
+  double bestd = best[q];
+  for (int c = 0; c < n; ++c) {
+    const int64_t row = (int64_t)cand[q * cap + c] - key_row_offset;
+    if (row < 0 || row >= nk_rows) continue;                       // (cannot happen; guards the address)
+    const uint8_t* b = Zk + (size_t)row * ld;
+    half8 bh[GPL][4], bl[GPL][4];
+#pragma unroll
+    for (int u = 0; u < GPL; ++u) {
+      const int g = min(lane + 64 * u, groups - 1);
+#pragma unroll
+      for (int piece = 0; piece < 4; ++piece) {
+        bh[u][piece] = *reinterpret_cast<const half8*>(b + (size_t)g * 128 + piece * 16);
+        bl[u][piece] = *reinterpret_cast<const half8*>(b + (size_t)g * 128 + 64 + piece * 16);
+      }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < GPL; ++u) {
+      if (lane + 64 * u < groups) {
+#pragma unroll
+        for (int piece = 0; piece < 4; ++piece)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const double d = (double)av[u][piece * 8 + j] - ((double)(float)bh[u][piece][j] + (double)(float)bl[u][piece][j]);
+            acc = fma(d, d, acc);
+          }
+      }
+    }
+    acc = wave_sum(acc);
+    bestd = fmin(bestd, acc);
+  }
+  if (lane == 0) best[q] = bestd;
+}
+
+__global__ void nn_finalize_kernel(const double* __restrict__ best, int64_t n, float* __restrict__ w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] = (float)sqrt(best[i]);
+}
+
+extern "C" int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream) {
+  AC_REQUIRE(best_d2 && w, "ac_nn_finalize: null pointer");
+  if (n <= 0) return AC_OK;
+  hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), best_d2, n, w);
+  return ac_check_launch("ac_nn_finalize");
+}
+
+extern "C" int ac_nn_refine(const void* Zk_hl32, int64_t nk_rows, const void* Zq_hl32, int64_t nq_rows, int D, const int32_t* cand,
+                            const int32_t* cand_count, int cap, int64_t key_row_offset, double* best_d2, int32_t* overflow_flag,
+                            void* stream) {
+  AC_REQUIRE(Zk_hl32 && Zq_hl32 && cand && cand_count && best_d2 && overflow_flag, "ac_nn_refine: null pointer");
+  AC_REQUIRE(nk_rows > 0 && nq_rows > 0 && D > 0 && D % 32 == 0 && cap > 0, "ac_nn_refine: bad shape");
+  AC_REQUIRE(D <= 32 * 64 * 4, "ac_nn_refine: D=%d above 8192", D);
+  const int gpl = (D / 32 + 63) / 64;               // hl32 groups per lane
+  const dim3 grid((unsigned)((nq_rows + 3) / 4));
+#define AC_REFINE(G)                                                                                                   \
+  hipLaunchKernelGGL(nn_refine_kernel<G>, grid, dim3(256), 0, as_stream(stream), static_cast<const uint8_t*>(Zk_hl32),   \
+                     nk_rows, static_cast<const uint8_t*>(Zq_hl32), nq_rows, D, cand, cand_count, cap, key_row_offset,     \
+                     best_d2, overflow_flag)
+  if (gpl <= 1) AC_REFINE(1);
+  else if (gpl == 2) AC_REFINE(2);
+  else AC_REFINE(4);
+#undef AC_REFINE
+  return ac_check_launch("ac_nn_refine");
 }
 
 // ------------------------------------------------------------ alpha softmax

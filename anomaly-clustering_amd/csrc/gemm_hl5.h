@@ -84,7 +84,11 @@ __device__ inline bool tile_of_square(int id, int tiles_m, int tiles_n, int grou
   return true;
 }
 
-template <class Epi, int NT, bool FLUSH, int WN = 2>
+// PLAIN: the operands are plain fp16 rows (128-byte line = 64 consecutive k values), not hl32: a stage is two
+// MFMAs per tile (first 32 k, second 32 k) instead of the three split-fp16 passes; the caller passes K / 2 as K so
+// that row bytes and stage count come out right.  (The approximate first pass of the pruned nearest-neighbour
+// search, alpha.hip.)
+template <class Epi, int NT, bool FLUSH, int WN = 2, bool PLAIN = false>
 __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
                                                      int id_lo, int id_hi, Epi epi) {
@@ -181,7 +185,10 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   barrier();                                     // B(0) is in registers everywhere: its slot may be refilled
   auto mfma3 = [&](f32x4& c, const half8& xh, const half8& xl, const half8& yh, const half8& yl) {
-    if constexpr (SWAP) {
+    if constexpr (PLAIN) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yl, c, 0, 0, 0);
+    } else if constexpr (SWAP) {
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl, xh, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xl, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh, xh, c, 0, 0, 0);
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
   }
 }
 
-template <class Epi, int NT = 8, bool FLUSH = false, int WN = 2>
+template <class Epi, int NT = 8, bool FLUSH = false, int WN = 2, bool PLAIN = false>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 4, int part = 0, int nparts = 1) {
   if (M <= 0 || N <= 0) return AC_OK;
@@ -334,11 +341,11 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   }
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl5: grid too large");
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
-  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH, WN>), LDS_BYTES, &attr_done)) return rc;
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, NT, FLUSH, WN, PLAIN>), LDS_BYTES, &attr_done)) return rc;
   long long lo = (total * part / nparts) & ~7LL;
   long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
-  hipLaunchKernelGGL((kernel<Epi, NT, FLUSH, WN>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
+  hipLaunchKernelGGL((kernel<Epi, NT, FLUSH, WN, PLAIN>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
                      group_m, (int)lo, (int)hi, epi);
   return ac_check_launch("gemm_hl5");

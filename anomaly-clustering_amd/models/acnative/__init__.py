@@ -54,6 +54,11 @@ SIGNATURES = {
     "ac_pair_fixed_shift": (_i, [_vp, _i64, _vp, _vp]),
     "ac_pair_accumulate": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i64, _vp, _vp, _vp]),
     "ac_pair_finalize": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),
+    "ac_h16_from_hl32": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "ac_nn_slack": (_i, [_vp, _vp, _vp, _vp]),
+    "ac_nn_candidates": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "ac_nn_refine": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "ac_nn_finalize": (_i, [_vp, _i64, _vp, _vp]),
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
@@ -489,6 +494,85 @@ def pair_reduce(minbuf, P, reduce, self_first=0, max_sq_t=None, n_keys=None):
     pair_accumulate(bits, P, reduce, self_first, shift, acc)
     inside = 0 <= self_first and self_first + nq <= nk
     return pair_finalize(acc, P, reduce, nk - 1 if (reduce == REDUCE_MEAN_OTHERS and inside) else nk, shift)
+
+
+# ---- supervised weights: pruned exact nearest neighbour (csrc/alpha.hip)
+NN_CAP = 64      # candidate slots per query patch and key set; a longer list sends that query to the exhaustive kernel
+
+
+def h16_from_packed(pk):
+    """The hi plane of a Packed block as plain fp16 rows: uint8 [n*P, D*2]."""
+    out = torch.empty((pk.n * pk.P, pk.D * 2), dtype=torch.uint8, device=pk.hl.device)
+    if pk.n:
+        _check(lib().ac_h16_from_hl32(pk.hl.data_ptr(), pk.n * pk.P, pk.D, out.data_ptr(), _stream()))
+    return out
+
+
+def nn_slack(max_sq_keys, max_sq_queries):
+    s = torch.empty(1, dtype=torch.float32, device=max_sq_keys.device)
+    _check(lib().ac_nn_slack(_dev(max_sq_keys, torch.float32, "max_sq_keys"), _dev(max_sq_queries, torch.float32, "max_sq_queries"),
+                             s.data_ptr(), _stream()))
+    return s
+
+
+class NNState:
+    """Running state of one pruned search: per query row the approximate minimum, the exact minimum so far, and
+    the candidate list of the key set being scanned."""
+
+    def __init__(self, nq_rows, device, cap=NN_CAP):
+        self.n, self.cap = nq_rows, cap
+        self.approx_min = torch.full((nq_rows,), INF_BITS, dtype=torch.int32, device=device)
+        self.best = torch.full((nq_rows,), float("inf"), dtype=torch.float64, device=device)
+        self.cand = torch.empty((nq_rows, cap), dtype=torch.int32, device=device)
+        self.count = torch.zeros((nq_rows,), dtype=torch.int32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def nn_scan(state, keys, keys_h16, queries, queries_h16, slack):
+    """One key set against all queries: pass 1 (candidates) + pass 2 (exact distances of the candidates)."""
+    if keys.n == 0 or queries.n == 0:
+        return
+    nk, nq, D = keys.n * keys.P, queries.n * queries.P, keys.D
+    state.count.zero_()
+    ev0, ev1 = _event_pair()
+    _check(lib().ac_nn_candidates(keys_h16.data_ptr(), keys.sq.data_ptr(), nk, queries_h16.data_ptr(), queries.sq.data_ptr(), nq, D,
+                                  slack.data_ptr(), state.approx_min.data_ptr(), state.cand.data_ptr(), state.count.data_ptr(),
+                                  state.cap, 0, _stream()))
+    if ev0 is not None:
+        ev1.record()
+        kernel_events.append(("nn_candidates", ev0, ev1, 1.0 * keys.n * queries.n, keys.P, D))
+    _check(lib().ac_nn_refine(keys.hl.data_ptr(), nk, queries.hl.data_ptr(), nq, D, state.cand.data_ptr(), state.count.data_ptr(),
+                              state.cap, 0, state.best.data_ptr(), state.overflow.data_ptr(), _stream()))
+
+
+def nn_fix_overflow(state, keys, queries, budget=1 << 30):
+    """Queries whose candidate list of this key set was longer than the slots (many bank patches within the error
+    bound of the nearest one - e.g. a uniform background): their exact minimum over the key set comes from the
+    exhaustive one-way split-fp16 kernel on a compact copy of just those rows.  Returns how many there were."""
+    over = state.count > state.cap
+    n_ovf = int(over.sum().item())
+    if n_ovf == 0:
+        return 0
+    idx = over.nonzero().flatten()
+    P, D = queries.P, queries.D
+    pad = (-n_ovf) % P                                   # the kernel's query axis comes in whole "images" of P rows
+    sel = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
+    Qc = Packed(queries.hl.index_select(0, sel).contiguous(), queries.sq.index_select(0, sel).contiguous(), sel.numel() // P, P, D)
+    acc = new_acc(sel.numel(), REDUCE_MIN_ALL, queries.hl.device)
+    c = max(1, int((budget // (4 * P * max(Qc.n, 1))) // P) or 1)     # key images per launch inside the minbuf budget
+    for k0 in range(0, keys.n, c):
+        mb = pair_block(keys.slice(k0, min(keys.n, k0 + c)), Qc)
+        pair_accumulate(mb, P, REDUCE_MIN_ALL, NO_SELF, None, acc)
+    d2 = acc[:n_ovf].view(torch.float32).double()
+    state.best[idx] = torch.minimum(state.best[idx], d2)
+    return n_ovf
+
+
+def nn_finalize(state, P):
+    w = torch.empty((state.n // P, P), dtype=torch.float32, device=state.best.device)
+    if state.n:
+        _check(lib().ac_nn_finalize(state.best.data_ptr(), state.n, w.data_ptr(), _stream()))
+    return w
 
 
 def alpha_softmax(w, tau, k=1.0):

@@ -39,8 +39,10 @@ and any block size give bit-identical w for the same Z.  On one GPU the ring sch
 "sub-blocks of my own shard" - that is how N = 2 000+ runs in a fixed memory budget.
 
 Supervised weights (min over the normal-image bank): the bank is sharded like the images, each rank
-packs its share, and the G bank shards go round the same ring, one-way blocks (local queries x that
-shard), min into a uint32 accumulator; no collective at the end.
+packs its share, and the G bank shards go round the same ring.  The min over all bank patches is a
+1-nearest-neighbour search, run as a pruned EXACT search: one MFMA launch per shard on the fp16 high halves
+(a third of the split-fp16 work) keeps the bank patches within a proven bound of the running minimum, and
+only those are measured exactly (alpha_weights_supervised; csrc/alpha.hip).  No collective at the end.
 
 `ops` is the compute seam: by default the HIP library (acnative + AnomalyClusteringCore); the
 world-size-2 gloo tests substitute a CPU stand-in to exercise the schedules and collectives.
@@ -151,6 +153,26 @@ class HipOps:
 
     def pair_finalize(self, acc, P, reduce, count, shift):
         return self.acnative.pair_finalize(acc, P, reduce, count, shift)
+
+    # ---- pruned exact nearest neighbour of the supervised mode
+    nn_prune = True
+    nn_cap = None            # candidate slots per query patch and bank shard (None: acnative.NN_CAP)
+
+    def h16(self, pk):
+        return self.acnative.h16_from_packed(pk)
+
+    def nn_slack(self, max_sq_keys, max_sq_queries):
+        return self.acnative.nn_slack(max_sq_keys, max_sq_queries)
+
+    def nn_state(self, nq_rows, device):
+        return self.acnative.NNState(nq_rows, device, self.nn_cap or self.acnative.NN_CAP)
+
+    def nn_scan(self, state, keys, keys_h16, queries, queries_h16, slack, budget=MINBUF_BYTES):
+        self.acnative.nn_scan(state, keys, keys_h16, queries, queries_h16, slack)
+        return self.acnative.nn_fix_overflow(state, keys, queries, budget)      # queries with too many near-ties
+
+    def nn_finalize(self, state, P):
+        return self.acnative.nn_finalize(state, P)
 
     def alpha_softmax(self, w, tau, k):
         return self.acnative.alpha_softmax(w, tau, k)
@@ -330,13 +352,34 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
 
 
 def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
-                             remote_bytes=REMOTE_BYTES):
+                             remote_bytes=REMOTE_BYTES, prune=True):
     """w fp32 [n_loc, P]: min over every bank image (utils.py:230-237 for every i of the shard).  The bank
-    shards go round the ring; each is multiplied one-way against the local queries, in sub-blocks."""
+    shards go round the ring.  Default: the pruned EXACT nearest-neighbour search - per shard one MFMA launch on
+    the fp16 high halves keeps, for every query patch, the bank patches within a proven error bound of the
+    running minimum, and only those (about a dozen, mostly collected before the running minimum has settled) are
+    measured exactly (fp64 on the split values).  A query patch with more near-ties than candidate slots is
+    re-measured by the exhaustive kernel on its own.  prune=False (or an ops seam without the kernels, or D not a
+    multiple of 64): exhaustive one-way split-fp16 blocks for everything, min into a uint32 accumulator."""
     P = pk_loc.P
     n_loc = pk_loc.n
-    acc = ops.new_acc(n_loc * P, MIN, device)
     counts = [b - a for a, b in bank_bounds]
+    m = sum(counts)
+    if prune and getattr(ops, "nn_prune", False) and pk_loc.D % 64 == 0:
+        mk, mq = ops.max_sq([pk_bank_loc], device), ops.max_sq([pk_loc], device)
+        if world > 1:                               # the bound must hold for every (query, bank patch) pair of the run
+            dist.all_reduce(mk, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(mq, op=dist.ReduceOp.MAX, group=group)
+        slack = ops.nn_slack(mk, mq)
+        state = ops.nn_state(n_loc * P, device)
+        q16 = ops.h16(pk_loc)
+        ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
+        for k in range(world):
+            keys = pk_bank_loc if k == 0 else ring.get(k)
+            if keys is None or keys.n == 0 or n_loc == 0:
+                continue
+            ops.nn_scan(state, keys, ops.h16(keys), pk_loc, q16, slack, budget)
+        return ops.nn_finalize(state, P)
+    acc = ops.new_acc(n_loc * P, MIN, device)
     ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
     c = block_images(P, budget)
     for k in range(world):
@@ -348,18 +391,18 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
             for k0, k1 in _subranges(0, keys.n, c):
                 mb = ops.pair_block(keys.slice(k0, k1), Q)
                 ops.pair_accumulate(mb, P, MIN, NO_SELF, None, acc[q0 * P: q1 * P])
-    m = sum(counts)
     return ops.pair_finalize(acc, P, MIN, m, None)
 
 
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
-                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES):
+                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
     budget / schedule / remote_bytes: memory budget of one matrix of minima, the unsupervised schedule ("auto" =
     "ring", or "slices") and the memory the ring may spend on receive buffers - results do not depend on any.
+    prune: supervised mode as a pruned exact nearest-neighbour search (default) or as exhaustive one-way blocks.
     Z_loc: the rank's embeddings from an earlier call on the same images (out["Z_loc"]): Z does not depend on
     the mode, so a run over several modes embeds the test set once (the reference re-embeds per mode and per tau,
     examples/main.py:346-366).
@@ -393,7 +436,7 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         blo, bhi = bb[rank]
         bank_loc = ops.embed(train_images[sel[blo:bhi]])
         w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget,
-                                         remote_bytes)
+                                         remote_bytes, prune)
         del bank_loc
     elif supervised == "unsupervised":
         w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule,

@@ -200,6 +200,31 @@ int ac_pair_accumulate(const uint32_t* minbuf, int64_t nk, int64_t ld, int64_t n
 int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift, float* w,
                      void* stream);
 
+/* Supervised weights as an EXACT pruned nearest-neighbour search (utils.py:230-237: the min runs over every patch of
+ * the normal-image bank, so only the nearest bank patch of each query patch needs an exact distance):
+ *   ac_h16_from_hl32: the hi plane of an hl32 image as plain fp16 rows [rows][K] (K % 64 == 0).
+ *   ac_nn_slack:      slack (device float [1]) = 2 delta, delta = the bound on |d~2 - d2| of pass 1, from the largest
+ *                     squared norms of the two sets (ac_max_f32).
+ *   ac_nn_candidates: pass 1, one MFMA launch on the fp16 hi planes (a third of the 3-pass work, half the bytes):
+ *                     keeps the running minimum approx_min[q] of d~2 over all launches (uint32 float bits, preset
+ *                     +inf) and appends to cand[q][.] every key row with d~2 <= running minimum + slack; cand_count
+ *                     [q] counts them (the caller zeroes it per key set; rows beyond `cap` are counted, not stored).
+ *   ac_nn_refine:     pass 2: best_d2[q] = min(best_d2[q], sum_k (q_k - key_k)^2) in fp64 on the split values of the
+ *                     hl32 images, over the stored candidates.  A query whose list was longer than cap
+ *                     (cand_count[q] > cap) is SKIPPED and overflow_flag (int32 [1]) set: the caller measures those
+ *                     queries against this key set with the exhaustive kernel (ac_pair_min_sq_packed, one-way).
+ *   ac_nn_finalize:   w = (float)sqrt(best_d2).
+ * The true nearest neighbour always survives pass 1 (proof in csrc/alpha.hip), whatever the order of the tiles. */
+int ac_h16_from_hl32(const void* hl32, int64_t rows, int K, void* dst_h16, void* stream);
+int ac_nn_slack(const float* max_sq_keys, const float* max_sq_queries, float* slack, void* stream);
+int ac_nn_candidates(const void* Zk_h16, const float* k_sq, int64_t nk_rows, const void* Zq_h16, const float* q_sq,
+                     int64_t nq_rows, int D, const float* slack, uint32_t* approx_min, int32_t* cand, int32_t* cand_count,
+                     int cap, int64_t key_row_offset, void* stream);
+int ac_nn_refine(const void* Zk_hl32, int64_t nk_rows, const void* Zq_hl32, int64_t nq_rows, int D, const int32_t* cand,
+                 const int32_t* cand_count, int cap, int64_t key_row_offset, double* best_d2, int32_t* overflow_flag,
+                 void* stream);
+int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream);
+
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
  *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;
  *   else alpha = k*exp(w/tau) / sum, computed max-shifted (same value, no overflow).

@@ -214,6 +214,60 @@ def test_block_schedules_are_bit_identical_on_one_gpu(dev):
                     oa.weights_supervised(torch.from_numpy(Zs), torch.from_numpy(Zb)).numpy())
 
 
+def _split_values(Z):
+    """What the kernels see of Z: hi + lo of the split-fp16 representation, as float64."""
+    hi = Z.to(torch.float16)
+    lo = (Z - hi.float()).to(torch.float16)
+    return hi.double() + lo.double()
+
+
+def test_pruned_nearest_neighbour_is_exact(dev):
+    """Supervised weights as a pruned search (fp16 first pass + exact re-measurement of the survivors) against
+    (a) the brute force over ALL bank patches in float64 on the same split values - the pruning must never lose the
+    nearest neighbour, so the two agree to fp64 round-off (1e-6 relative after the sqrt and the cast) - and
+    (b) the exhaustive split-fp16 path (2e-5, its own distance from the truth)."""
+    from patchcore.pipeline import run_category
+    ops = _IdentityOps()
+    for (nq, nk, P, D, salt) in [(4, 5, 100, 256, 71), (2, 3, 784, 4096, 72), (3, 1, 67, 64, 73)]:
+        Zq, _ = clustered_embeddings(nq, P, D, 3, salt=salt)
+        Zk, _ = clustered_embeddings(nk, P, D, 1, salt=salt + 100)
+        tq, tk = torch.from_numpy(Zq).to(dev), torch.from_numpy(Zk).to(dev)
+        pruned = run_category(ops, tq, "supervised", tau=1.0, train_images=tk, train_ratio=float(nk) / nq + 1)["w_loc"]
+        exhaustive = run_category(ops, tq, "supervised", tau=1.0, train_images=tk, train_ratio=float(nk) / nq + 1,
+                                  prune=False)["w_loc"]
+        a, b = _split_values(tq).reshape(nq * P, D), _split_values(tk).reshape(nk * P, D)
+        d2 = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+        brute = d2.clamp_min(0).min(1)[0].sqrt().reshape(nq, P)
+        np.testing.assert_allclose(pruned.double().cpu().numpy(), brute.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        assert (pruned - exhaustive).abs().max().item() <= 2e-5, (nq, nk, P, D)
+
+
+def test_pruned_search_re_measures_queries_whose_candidate_lists_overflow(dev):
+    """A bank made of copies of one image gives every query patch many equally near bank patches; with one candidate
+    slot the lists overflow and those queries go through the exhaustive kernel on a compact copy: their answer is
+    the exhaustive path's, bit for bit; with room for the ties the pruned answer agrees to 2e-5."""
+    from patchcore.pipeline import run_category
+    Zq, _ = clustered_embeddings(3, 100, 128, 2, salt=81)
+    one, _ = clustered_embeddings(1, 100, 128, 1, salt=82)
+    bank = np.repeat(one, 6, axis=0)
+    tq, tk = torch.from_numpy(Zq).to(dev), torch.from_numpy(bank).to(dev)
+    ops = _IdentityOps()
+    ops.nn_cap = 1
+    tight = run_category(ops, tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0)["w_loc"]
+    exhaustive = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0, prune=False)["w_loc"]
+    assert torch.equal(tight, exhaustive)                       # every query has >= 6 ties: all of them overflowed
+    roomy = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0)["w_loc"]
+    assert (roomy - exhaustive).abs().max().item() <= 2e-5
+    # a mixed case: two slots, a bank with one duplicated image - some queries overflow, some do not
+    mixed_bank = np.concatenate([one, one, clustered_embeddings(2, 100, 128, 1, salt=83)[0]])
+    ops2 = _IdentityOps()
+    ops2.nn_cap = 2
+    tm = torch.from_numpy(mixed_bank).to(dev)
+    got = run_category(ops2, tq, "supervised", tau=1.0, train_images=tm, train_ratio=2.0)["w_loc"]
+    ref = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tm, train_ratio=2.0, prune=False)["w_loc"]
+    assert (got - ref).abs().max().item() <= 2e-5
+
+
 def test_fixed_point_scale_follows_the_data(dev):
     """The shift of the 64-bit fixed-point sum comes from n_keys * 2 sqrt(max |z|^2): capped at 40 for ordinary
     data, lower when many keys or large norms would overflow 2^62 - and w barely notices (resolution 2^-shift)."""
