@@ -559,7 +559,7 @@ def nn_fix_overflow(state, keys, queries, budget=1 << 30):
     sel = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
     Qc = Packed(queries.hl.index_select(0, sel).contiguous(), queries.sq.index_select(0, sel).contiguous(), sel.numel() // P, P, D)
     acc = new_acc(sel.numel(), REDUCE_MIN_ALL, queries.hl.device)
-    c = max(1, int((budget // (4 * P * max(Qc.n, 1))) // P) or 1)     # key images per launch inside the minbuf budget
+    c = max(1, int(budget // (4 * P * max(Qc.n, 1))))                 # key images per launch: minbuf [c, Qc.n * P] in the budget
     for k0 in range(0, keys.n, c):
         mb = pair_block(keys.slice(k0, min(keys.n, k0 + c)), Qc)
         pair_accumulate(mb, P, REDUCE_MIN_ALL, NO_SELF, None, acc)
