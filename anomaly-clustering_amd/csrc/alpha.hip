@@ -388,7 +388,7 @@ extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64
 struct EpiNNCand {
   const float* key_sq;    // [M] bank rows
   const float* qry_sq;    // [N] query rows
-  const float* slack;     // device [1]
+  const float* slack;     // device [2]: relative (x |query|) and absolute part
   unsigned* approx_min;   // [N] running min of d~2 (float bits), across launches
   int* cand;              // [N][cap] bank-row indices (+ row_offset)
   int* count;             // [N]
@@ -396,7 +396,7 @@ struct EpiNNCand {
   template <class F>
   __device__ void operator()(const F& f, int m_wave, int n_wave, int lane, bool = false) const {
     if (m_wave >= M) return;                      // wave-uniform
-    const float sl = slack[0];
+    const float sl_rel = slack[0], sl_abs = slack[1];      // slack of query a: sl_rel * |a| + sl_abs
     float ksq[F::NT][F::NR];
 #pragma unroll
     for (int mi = 0; mi < F::NT; ++mi)
@@ -422,7 +422,7 @@ struct EpiNNCand {
       unsigned old = 0x7f800000u;
       if (F::first_row_group(lane) && col < N) old = atomicMin(approx_min + col, __float_as_uint(mn));
       old = __shfl(old, lane & (F::TW - 1), 64);  // the lane of the first row group that owns this column
-      const float thr = fminf(__uint_as_float(old), mn) + sl;
+      const float thr = fminf(__uint_as_float(old), mn) + (sl_rel * sqrtf(qs) * 1.000001f + sl_abs);
       if (col < N) {
 #pragma unroll
         for (int mi = 0; mi < F::NT; ++mi)
@@ -460,11 +460,13 @@ extern "C" int ac_h16_from_hl32(const void* hl32, int64_t rows, int K, void* dst
 }
 
 __global__ void nn_slack_kernel(const float* __restrict__ max_sq_k, const float* __restrict__ max_sq_q, float* __restrict__ slack) {
-  // 2 delta, delta = 2 * (2^-10 + 2^-22) |a| |b| (dropped cross terms) + 2 * 160 * 2^-24 |a| |b| (fp32 accumulation of
-  // 128 MFMA steps, rigorous gamma bound), rounded up generously
-  const double na = sqrt((double)max_sq_k[0]), nb = sqrt((double)max_sq_q[0]);
-  // + an absolute term for values in fp16's subnormal range, whose low halves are bounded by 2^-25 instead of 2^-11 |x|
-  slack[0] = (float)(2.0 * 2.0 * (9.77e-4 + 2.0e-5) * na * nb * 1.01 + 1.0e-5 * (na + nb)) + 1e-30f;
+  // slack of a query a = 2 delta(a), delta(a) = 2 * (2^-10 + 2^-22) |a| |b|max (dropped cross terms) + 2 * 160 * 2^-24 |a| |b|max
+  // (fp32 accumulation of 128 MFMA steps, rigorous gamma bound), rounded up; both pairs of the proof share the query, so
+  // the bound may use ITS norm.  slack[0] multiplies |a|; slack[1] is an absolute term for values in fp16's subnormal
+  // range, whose low halves are bounded by 2^-25 instead of 2^-11 |x|.
+  const double nb = sqrt((double)max_sq_k[0]), na = sqrt((double)max_sq_q[0]);
+  slack[0] = (float)(2.0 * 2.0 * (9.77e-4 + 2.0e-5) * nb * 1.01);
+  slack[1] = (float)(1.0e-5 * (na + nb)) + 1e-30f;
 }
 
 extern "C" int ac_nn_slack(const float* max_sq_keys, const float* max_sq_queries, float* slack, void* stream) {

@@ -509,7 +509,7 @@ def h16_from_packed(pk):
 
 
 def nn_slack(max_sq_keys, max_sq_queries):
-    s = torch.empty(1, dtype=torch.float32, device=max_sq_keys.device)
+    s = torch.empty(2, dtype=torch.float32, device=max_sq_keys.device)
     _check(lib().ac_nn_slack(_dev(max_sq_keys, torch.float32, "max_sq_keys"), _dev(max_sq_queries, torch.float32, "max_sq_queries"),
                              s.data_ptr(), _stream()))
     return s

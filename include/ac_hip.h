@@ -203,8 +203,9 @@ int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, 
 /* Supervised weights as an EXACT pruned nearest-neighbour search (utils.py:230-237: the min runs over every patch of
  * the normal-image bank, so only the nearest bank patch of each query patch needs an exact distance):
  *   ac_h16_from_hl32: the hi plane of an hl32 image as plain fp16 rows [rows][K] (K % 64 == 0).
- *   ac_nn_slack:      slack (device float [1]) = 2 delta, delta = the bound on |d~2 - d2| of pass 1, from the largest
- *                     squared norms of the two sets (ac_max_f32).
+ *   ac_nn_slack:      slack (device float [2]): the candidate window of a query a is slack[0] * |a| + slack[1] = 2 delta(a),
+ *                     delta(a) = the bound on |d~2 - d2| of pass 1 for that query, from the largest squared norms of
+ *                     the two sets (ac_max_f32).
  *   ac_nn_candidates: pass 1, one MFMA launch on the fp16 hi planes (a third of the 3-pass work, half the bytes):
  *                     keeps the running minimum approx_min[q] of d~2 over all launches (uint32 float bits, preset
  *                     +inf) and appends to cand[q][.] every key row with d~2 <= running minimum + slack; cand_count

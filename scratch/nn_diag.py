@@ -22,7 +22,7 @@ else:   # real pipeline embeddings (random-init ViT on synthetic images), test v
 q, k = acnative.pack_images(Z), acnative.pack_images(B)
 q16, k16 = acnative.h16_from_packed(q), acnative.h16_from_packed(k)
 slack = acnative.nn_slack(acnative.max_sq([k], dev), acnative.max_sq([q], dev))
-print("slack", slack.item(), "max_sq", acnative.max_sq([k], dev).item())
+print("slack", slack.tolist(), "max_sq", acnative.max_sq([k], dev).item())
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
 for cap in (32, 256):
