@@ -11,6 +11,7 @@ the category size N.  --config selects the BASELINE.json workload
     3        all 15 MVTec-AD-shaped categories one after another (sum N = 1725), unsupervised;
              value = 1725 / (time of one pass over all 15); per-category table in `per_category`
     4        as 3 but supervised, train_ratio 1.0: a bank of M = N_test seeded train images per category
+             (the bank search runs as the pruned exact nearest-neighbour search)
     5a       one synthetic category of --n images (default 10 000), `average` weights (extract + X + pdist)
     5b       the same, unsupervised tau = 1: the N x N pair stress.  At N = 10 000 one step is 5.0e17 FLOP
              (about 10 minutes of MFMA work per GPU on 8 GPUs); `--n 2000` (2.0e16 FLOP, ~25 s on one GPU)
