@@ -373,12 +373,29 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
         state = ops.nn_state(n_loc * P, device)
         q16 = ops.h16(pk_loc)
         ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
+        exhaustive_acc = None                       # set once pruning has proved useless on this data (see below)
+        c = block_images(P, budget)
         for k in range(world):
             keys = pk_bank_loc if k == 0 else ring.get(k)
             if keys is None or keys.n == 0 or n_loc == 0:
                 continue
-            ops.nn_scan(state, keys, ops.h16(keys), pk_loc, q16, slack, budget)
-        return ops.nn_finalize(state, P)
+            if exhaustive_acc is None:
+                n_ovf = ops.nn_scan(state, keys, ops.h16(keys), pk_loc, q16, slack, budget)
+                # More than half of the query patches had more near-ties than candidate slots (e.g. a bank of
+                # near-identical images): the first pass buys nothing here, so the remaining shards go straight
+                # to the exhaustive blocks - the regression against prune=False is bounded by this one pass.
+                if 2 * n_ovf > n_loc * P:
+                    exhaustive_acc = ops.new_acc(n_loc * P, MIN, device)
+            else:
+                for q0, q1 in _subranges(0, n_loc, c):
+                    Q = pk_loc.slice(q0, q1)
+                    for k0, k1 in _subranges(0, keys.n, c):
+                        mb = ops.pair_block(keys.slice(k0, k1), Q)
+                        ops.pair_accumulate(mb, P, MIN, NO_SELF, None, exhaustive_acc[q0 * P: q1 * P])
+        w = ops.nn_finalize(state, P)
+        if exhaustive_acc is not None:
+            w = torch.minimum(w, ops.pair_finalize(exhaustive_acc, P, MIN, m, None))
+        return w
     acc = ops.new_acc(n_loc * P, MIN, device)
     ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
     c = block_images(P, budget)

@@ -101,7 +101,7 @@ def test_more_ranks_than_images(dev):
             np.testing.assert_allclose(a, ref["alpha"].cpu().numpy(), rtol=2e-4, atol=1e-8)
 
 
-def _worker_engine(rank, world, init_file, mode, out_dir, schedule, budget):
+def _worker_engine(rank, world, init_file, mode, out_dir, schedule, budget, ties=False):
     """The alpha engine alone (embeddings given), so that ranks can be compared BIT FOR BIT."""
     sys.path[:0] = [ROOT, MODELS, os.path.join(ROOT, "tests")]
     from patchcore.pipeline import HipOps, run_category
@@ -113,8 +113,11 @@ def _worker_engine(rank, world, init_file, mode, out_dir, schedule, budget):
     ops.embed = lambda images: images.contiguous()
     Zs, _ = clustered_embeddings(7, 100, 256, 3, salt=51)
     Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=52)
+    if ties:                                   # a bank of copies of one image, one candidate slot: every list overflows
+        Zb = np.repeat(Zb[:1], 6, axis=0)
+        ops.nn_cap = 1
     out = run_category(ops, torch.from_numpy(Zs).to(dev), mode, tau=1.0, train_images=torch.from_numpy(Zb).to(dev),
-                       schedule=schedule, budget=budget)
+                       schedule=schedule, budget=budget, train_ratio=1.0)
     np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].cpu().numpy())
     np.save(os.path.join(out_dir, "w_%d.npy" % rank), out["w_loc"].cpu().numpy())
     np.save(os.path.join(out_dir, "X_%d.npy" % rank), out["X"])
@@ -148,3 +151,26 @@ def test_streaming_schedules_match_one_rank_bitwise(dev, world, mode, schedule, 
             assert np.array_equal(np.load(os.path.join(d, "X_%d.npy" % r)), ref["X"]), r
             lo, hi = bounds[r]
             assert np.array_equal(np.load(os.path.join(d, "w_%d.npy" % r)), ref["w_loc"][lo:hi].cpu().numpy()), r
+
+
+def test_pruned_search_gives_up_on_tie_heavy_banks_across_shards(dev):
+    """Three ranks, a bank of six copies of one image (two per rank), one candidate slot: on its first bank shard every
+    query overflows (re-measured exhaustively on the spot), so the remaining shards skip the first pass altogether.
+    The answer is the exhaustive path's, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patchcore.pipeline import HipOps, run_category, shard_bounds
+    from _synth import clustered_embeddings
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    Zs, _ = clustered_embeddings(7, 100, 256, 3, salt=51)
+    Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=52)
+    Zb = np.repeat(Zb[:1], 6, axis=0)
+    ref = run_category(ops, torch.from_numpy(Zs).to(dev), "supervised", tau=1.0, train_images=torch.from_numpy(Zb).to(dev),
+                       train_ratio=1.0, prune=False)
+    bounds = shard_bounds(7, 3)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_engine, args=(3, os.path.join(d, "rdzv"), "supervised", d, "auto", 1 << 30, True), nprocs=3, join=True)
+        for r in range(3):
+            lo, hi = bounds[r]
+            assert np.array_equal(np.load(os.path.join(d, "w_%d.npy" % r)), ref["w_loc"][lo:hi].cpu().numpy()), r
+            assert np.array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].cpu().numpy()), r
