@@ -159,3 +159,36 @@ def test_attention_ignores_the_pad_rows_of_its_buffers(dev):
             ws.fill_(0xFF)
         again = m.blocks[0](x)
     assert torch.isfinite(again).all() and torch.equal(again, ref)
+
+
+def test_patch16_backbone_through_the_whole_embedding(dev, monkeypatch):
+    """the other DINO names of the registry.  `dino_vitbase16` builds vit_base with 16x16 patches
+    (reference backbones.py:70): 197 tokens, a 14x14 patch grid, attention tiles with 5 real keys in the last tile.
+    Taps of blocks 10/11 and the aggregated Z (3x3 unfold on the 14x14 grid, 6912 -> 2048 per layer - the register
+    path of the aggregation kernel - concat to 4096) against the oracle."""
+    import patchcore.backbones
+    import patchcore.common as common
+    import patchcore.sampler
+    from patchcore.patchcore import AnomalyClusteringCore
+    from oracle import vit as ovit, aggregate as oagg
+    monkeypatch.setenv("AC_BACKBONE_SEED", "4")
+    model = patchcore.backbones.load("dino_vitbase16")
+    assert model.pos_embed.shape == (1, 197, 768) and model.weights_source == "random-init(seed=4)"
+    core = AnomalyClusteringCore(dev)
+    core.load(backbone=model, layers_to_extract_from=["blocks.10", "blocks.11"], device=dev, input_shape=(3, 224, 224),
+              pretrain_embed_dimension=2048, target_embed_dimension=4096, patchsize=3,
+              featuresampler=patchcore.sampler.IdentitySampler(), nn_method=common.FaissNN(False, 4))
+    images = torch.from_numpy(gaussish_tensor((3, 3, 224, 224), salt=14, scale=1.5))
+    Z = core.embed_device(images.to(dev), batch_size=2)               # two batches: in-place rows of one Z
+    assert Z.shape == (3, 196, 4096)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    taps = ovit.forward_taps(sd, images, taps=(10, 11))
+    feats = core.forward_modules["feature_aggregator"](images.to(dev))
+    for i in (10, 11):
+        r = taps[i]
+        err = (feats["blocks.%d" % i].cpu() - r).abs()
+        assert torch.all(err <= ATOL + RTOL * r.abs()), (i, err.max())
+    Z_ref = oagg.aggregate([taps[10], taps[11]], 3, 2048, 4096)[0].reshape(3, 196, 4096)
+    zerr = (Z.cpu() - Z_ref).abs()
+    print("patch 16: Z max err %.2e" % zerr.max().item())
+    assert torch.all(zerr <= 2e-4 + 2e-4 * Z_ref.abs())
