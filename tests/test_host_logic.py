@@ -291,6 +291,12 @@ def test_bench_workloads_match_baseline_configs():
     name, items, mode = build("2-pill")
     assert items[0]["category"] == "pill" and len(items[0]["labels"]) == 167
     name, items, mode = build("5a", n=40)
-    assert mode == "average" and items[0]["images"].shape[0] == 40 and len(set(items[0]["labels"])) == 5
+    assert mode == "average" and items[0]["images"].shape == (40, 3, 224, 224) and len(set(items[0]["labels"])) == 5
+    assert items[0]["images"][0:40].shape == (40, 3, 224, 224)        # a ShardView: this rank's shard only
+    with pytest.raises(IndexError):
+        items[0]["images"][0:7]
+    ns = argparse.Namespace(config="5b", category=None, n=10, tau=1.0)
+    shard = bench.build_workload(ns, cpu, rank=1, world=4)[1][0]["images"]
+    assert shard.shape[0] == 10 and shard[3:6].shape[0] == 3
     assert build("5b", n=12)[2] == "unsupervised"
     assert bench.CONFIGS == ("2", "2-pill", "3", "4", "5a", "5b")
