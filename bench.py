@@ -21,6 +21,7 @@ Random-init ViT-B/8 weights of the named architecture (no checkpoint or dataset 
 --gpus G the images of every category are sharded over G ranks (strong scaling of the same workload).
 
     python bench.py                      # 1 GPU, config 2
+    python bench.py --gpus 8             # starts its own 8 ranks (fresh child processes, one per GPU, RCCL)
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
@@ -54,7 +55,9 @@ CONFIGS = ("2", "2-pill", "3", "4", "5a", "5b")
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU). Without a torchrun environment bench.py starts them itself; default: "
+                         "WORLD_SIZE, else 1")
     ap.add_argument("--steps", type=int, default=None, help="default: 3 (configs 2*), 1 otherwise")
     ap.add_argument("--warmup", type=int, default=None, help="default: 1 (configs 2*, 3, 4), 0 for config 5")
     ap.add_argument("--config", default="2", choices=CONFIGS)
@@ -65,7 +68,8 @@ def parse():
     ap.add_argument("--budget-mb", type=int, default=1024, help="memory budget of one matrix of minima")
     ap.add_argument("--schedule", default="auto", choices=["auto", "slices", "ring"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=32, help="category size of the measured CPU baseline")
+    ap.add_argument("--cpu-n", type=int, nargs="+", default=[32, 83],
+                    help="category sizes at which the CPU baseline is MEASURED (N=83 takes about a minute of host time)")
     ap.add_argument("--no-extras", action="store_true", help="skip h2d_inclusive / ward_metrics_ms / stage_ms")
     return ap.parse_args()
 
@@ -119,47 +123,75 @@ def _cpu_run(sd, images, n):
     return t1 - t0, t2 - t1, t3 - t2
 
 
-def cpu_baseline(n_meas, n_quote, category):
-    """Measured: N = n_meas images of the category end to end at the best thread count of a short sweep, and a
-    1-thread run on a smaller sample.  Extrapolated (labelled): the quoted workload size n_quote from the
-    measured per-image and per-pair costs."""
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; None when it does not say."""
+    try:
+        seen, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":", 1)[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(sizes, n_quote, category, probe_n=8):
+    """The CPU oracle (a port of the reference's arithmetic, oracle/) timed on this host.
+    MEASURED end to end at every category size in `sizes` (default 32 and the real category size 83) at the thread
+    count that wins a sweep on a probe of `probe_n` images (probe_n * (probe_n - 1) ordered pairs), plus a 1-thread
+    run on 5 images.  `value` is the run at the workload's own size n_quote when it is among `sizes`; otherwise the
+    largest measured size, and the workload size is EXTRAPOLATED (labelled) from its per-image / per-pair costs."""
     import patchcore.vision_transformer as vits
     from patchcore.datasets import synthetic
     torch.manual_seed(0)
     model = vits.vit_base(patch_size=8, num_classes=0)
     sd = {k: v.detach() for k, v in model.state_dict().items()}
-    labels = synthetic.category_labels(category if category in synthetic.TEST_HISTOGRAMS else "bottle")
-    step = max(1, len(labels) // n_meas)
-    labels = labels[::step][:n_meas]                          # spread over the classes
-    n_meas = len(labels)
-    images = synthetic.make_images(category, labels)
+    cat = category if category in synthetic.TEST_HISTOGRAMS else "bottle"
+    all_labels = synthetic.category_labels(cat)
+
+    def sample(n):
+        step = max(1, len(all_labels) // n)
+        lab = all_labels[::step][:n]                          # spread over the classes
+        return lab, synthetic.make_images(cat, lab)
+
     nproc = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
+    _, probe = sample(probe_n)
     sweep = {}
     for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= nproc} | {min(nproc, default_threads)}):
         torch.set_num_threads(th)
-        e, a, t = _cpu_run(sd, images, 3)                     # probe: 3 images, 6 ordered pairs
-        sweep[th] = e + a + t
+        sweep[th] = sum(_cpu_run(sd, probe, probe.shape[0]))
     best = min(sweep, key=sweep.get)
-    torch.set_num_threads(best)
-    e, a, t = _cpu_run(sd, images, n_meas)
-    total = e + a + t
-    per_img, per_pair = (e + t) / n_meas, a / max(1, n_meas * (n_meas - 1))
+    runs = []
+    for n in sorted({min(int(v), len(all_labels)) for v in sizes}):
+        lab, images = sample(n)
+        torch.set_num_threads(best)
+        e, a, t = _cpu_run(sd, images, len(lab))
+        runs.append({"n": len(lab), "images_per_sec": len(lab) / (e + a + t), "seconds": e + a + t,
+                     "s_per_image": (e + t) / len(lab), "s_per_pair": a / max(1, len(lab) * (len(lab) - 1))})
     torch.set_num_threads(1)
-    n1 = min(n_meas, 5)
-    e1, a1, t1 = _cpu_run(sd, images, n1)
+    e1, a1, t1 = _cpu_run(sd, probe, 5)
     torch.set_num_threads(default_threads)
-    quote = n_quote / (n_quote * per_img + n_quote * (n_quote - 1) * per_pair)
-    return {"value": n_meas / total, "unit": "images/sec", "cores": best, "kind": "port",
-            "sample": "MEASURED: N=%d images of the %s-shaped category end to end on the host (ViT+aggregate batch 1, "
-                      "all %d ordered alpha pairs, weighted average, pdist) at %d torch threads = best of the sweep %s "
-                      "(seconds for a 3-image probe)" % (n_meas, category, n_meas * (n_meas - 1), best,
-                                                         {k: round(v, 2) for k, v in sweep.items()}),
-            "n": n_meas, "seconds": total, "s_per_image": per_img, "s_per_pair": per_pair,
-            "one_thread": {"n": n1, "images_per_sec": n1 / (e1 + a1 + t1), "seconds": e1 + a1 + t1},
-            "extrapolated_to_workload": {"n": n_quote, "images_per_sec": quote,
-                                         "rule": "N / (N * s_per_image + N(N-1) * s_per_pair), EXTRAPOLATED"},
-            "nproc": nproc, "cpu_model": _cpu_model(), "torch_default_threads": default_threads}
+    at_size = [r for r in runs if r["n"] == n_quote]
+    head = at_size[0] if at_size else runs[-1]
+    out = {"value": head["images_per_sec"], "unit": "images/sec", "cores": best, "threads": best, "kind": "port",
+           "sample": "MEASURED: N=%d images of the %s-shaped category end to end on the host (ViT+aggregate batch 1, all "
+                     "%d ordered alpha pairs, weighted average, pdist) at %d torch threads = best of the sweep %s (seconds "
+                     "for a %d-image probe: %d ordered pairs)"
+                     % (head["n"], cat, head["n"] * (head["n"] - 1), best, {k: round(v, 2) for k, v in sweep.items()},
+                        probe.shape[0], probe.shape[0] * (probe.shape[0] - 1)),
+           "n": head["n"], "seconds": head["seconds"], "s_per_image": head["s_per_image"], "s_per_pair": head["s_per_pair"],
+           "measured_sizes": runs,
+           "one_thread": {"n": 5, "images_per_sec": 5 / (e1 + a1 + t1), "seconds": e1 + a1 + t1},
+           "nproc": nproc, "physical_cores": _physical_cores(), "cpu_model": _cpu_model(),
+           "torch_default_threads": default_threads}
+    if not at_size:
+        out["extrapolated_to_workload"] = {
+            "n": n_quote, "images_per_sec": n_quote / (n_quote * head["s_per_image"] + n_quote * (n_quote - 1) * head["s_per_pair"]),
+            "rule": "N / (N * s_per_image + N(N-1) * s_per_pair) from the N=%d run, EXTRAPOLATED" % head["n"]}
+    return out
 
 
 # ------------------------------------------------------------------ workloads
@@ -231,13 +263,98 @@ def build_workload(args, dev, rank=0, world=1):
     return name, items, mode
 
 
+# ------------------------------------------------------------------ self-launch of the ranks
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, child_cmd, visible_devices=None, poll_s=0.2):
+    """`bench.py --gpus n` started WITHOUT a torchrun environment: start n fresh child processes (one per GPU, the
+    same command line each) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's
+    single JSON line on stdout, and return a non-zero code if any child fails (the survivors are ended by PID).
+
+    The parent never touches the GPU: it only COUNTS devices (torch.cuda.device_count() does not initialise HIP on
+    this image) and never re-execs itself.  Fewer than n visible devices is an error, not a downgrade."""
+    import subprocess
+    if visible_devices is None:
+        visible_devices = torch.cuda.device_count()
+    if visible_devices < n:
+        print("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to run fewer ranks than asked"
+              % (n, visible_devices), file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        # rank 0's stdout carries the JSON line; the other ranks print nothing there, but keep them off our stdout
+        procs.append(subprocess.Popen(list(child_cmd), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=(r == 0)))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+        time.sleep(poll_s)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+                break
+    if failed is not None:
+        for p in procs:                                    # a dead rank leaves the others waiting in a collective
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        print("bench.py --gpus %d: rank %d exited with code %s" % (n, failed[0], failed[1]), file=sys.stderr)
+        return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
+    reader.join(timeout=10)
+    result = None
+    for ln in lines:
+        s = ln.strip()
+        if s.startswith("{"):
+            try:
+                json.loads(s)
+                result = s
+            except ValueError:
+                pass
+        elif s:
+            print(s, file=sys.stderr)
+    if result is None:
+        print("bench.py --gpus %d: rank 0 printed no JSON line" % n, file=sys.stderr)
+        return 1
+    print(result)
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: this process becomes the launcher and makes no GPU call at all
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; the number of ranks must be the number asked for"
+                         % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -247,10 +364,8 @@ def main():
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)
         torch.cuda.synchronize()
-        if int(probe.item()) != world:
+        if int(probe.item()) != world or dist.get_world_size() != world:
             raise SystemExit("RCCL all-reduce smoke failed: %r" % probe.item())
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     steps = args.steps if args.steps is not None else (3 if args.config.startswith("2") else 1)
     warmup = args.warmup if args.warmup is not None else (0 if args.config.startswith("5") else 1)
 
