@@ -176,6 +176,34 @@ __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+// Preset of a matrix of minima / an accumulator (+inf bits, or zeros for the int64 sums as 2 words each): the engine's
+// buffers are initialised by the library itself, on the launch stream, between its own kernels.
+extern "C" int ac_fill_u32(uint32_t* dst, int64_t count, uint32_t value, void* stream) {
+  AC_REQUIRE(dst || count <= 0, "ac_fill_u32: null pointer");
+  AC_REQUIRE(((uintptr_t)dst & 3) == 0, "ac_fill_u32: dst must be 4-byte aligned");
+  if (count <= 0) return AC_OK;
+  const int64_t blocks = (count + 1023) / 1024;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream), dst,
+                     (size_t)count, value);
+  return ac_check_launch("ac_fill_u32");
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, size_t n, unsigned long long v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+extern "C" int ac_fill_u64(uint64_t* dst, int64_t count, uint64_t value, void* stream) {
+  AC_REQUIRE(dst || count <= 0, "ac_fill_u64: null pointer");
+  AC_REQUIRE(((uintptr_t)dst & 7) == 0, "ac_fill_u64: dst must be 8-byte aligned");
+  if (count <= 0) return AC_OK;
+  const int64_t blocks = (count + 1023) / 1024;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<unsigned long long*>(dst), (size_t)count, (unsigned long long)value);
+  return ac_check_launch("ac_fill_u64");
+}
+
 // ---------------------------------------------------- from min d2 to the weights w
 // minbuf[j][col] (min d2 between query patch `col` and key image j) -> w.  The unsupervised mean runs
 // over ALL key images of the category, which a large or sharded problem sees block by block, on different
@@ -388,7 +416,7 @@ extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64
 struct EpiNNCand {
   const float* key_sq;    // [M] bank rows
   const float* qry_sq;    // [N] query rows
-  const float* slack;     // device [2]: relative (x |query|) and absolute part
+  const float* slack;     // device [3]: relative (x |query|) and absolute part (+ the out-of-range flag, host side)
   unsigned* approx_min;   // [N] running min of d~2 (float bits), across launches
   int* cand;              // [N][cap] bank-row indices (+ row_offset)
   int* count;             // [N]
@@ -467,6 +495,10 @@ __global__ void nn_slack_kernel(const float* __restrict__ max_sq_k, const float*
   const double nb = sqrt((double)max_sq_k[0]), na = sqrt((double)max_sq_q[0]);
   slack[0] = (float)(2.0 * 2.0 * (9.77e-4 + 2.0e-5) * nb * 1.01);
   slack[1] = (float)(1.0e-5 * (na + nb)) + 1e-30f;
+  // The bound assumes finite fp16 high halves: |x| < 65504 for every element, which |row| < 65504 guarantees.  Outside
+  // that range (or with a non-finite norm) the first pass may see inf - inf; slack[2] != 0 tells the caller to run the
+  // exhaustive split-fp16 blocks instead, which surface inf / NaN as the reference's cdist does.
+  slack[2] = (nb < 65504.0 && na < 65504.0) ? 0.f : 1.f;      // false for NaN norms as well
 }
 
 extern "C" int ac_nn_slack(const float* max_sq_keys, const float* max_sq_queries, float* slack, void* stream) {
@@ -494,12 +526,17 @@ template <int GPL>
 __global__ __launch_bounds__(256) void nn_refine_kernel(const uint8_t* __restrict__ Zk, int64_t nk_rows, const uint8_t* __restrict__ Zq,
                                                         int64_t nq_rows, int D, const int* __restrict__ cand,
                                                         const int* __restrict__ count, int cap, int64_t key_row_offset,
-                                                        double* __restrict__ best, int* __restrict__ overflow) {
+                                                        double* __restrict__ best, int* __restrict__ overflow,
+                                                        int* __restrict__ overflow_rows, const float* __restrict__ slack) {
   const int lane = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq_rows) return;                                        // wave-uniform
   int n = count[q];
-  if (n > cap) { if (lane == 0) *overflow = 1; return; }           // the caller re-measures this query exhaustively
+  if (n > cap || (slack && slack[2] != 0.f)) {                     // the caller re-measures this query exhaustively
+    // (slack[2]: norms outside the fp16 range of the first pass - nothing it produced can be trusted)
+    if (lane == 0) { *overflow = 1; if (overflow_rows) overflow_rows[q] = 1; }
+    return;
+  }
   if (n == 0) return;
   const int groups = D / 32;
   const size_t ld = (size_t)D * 4;
@@ -564,7 +601,7 @@ extern "C" int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* 
 
 extern "C" int ac_nn_refine(const void* Zk_hl32, int64_t nk_rows, const void* Zq_hl32, int64_t nq_rows, int D, const int32_t* cand,
                             const int32_t* cand_count, int cap, int64_t key_row_offset, double* best_d2, int32_t* overflow_flag,
-                            void* stream) {
+                            int32_t* overflow_rows, const float* slack, void* stream) {
   AC_REQUIRE(Zk_hl32 && Zq_hl32 && cand && cand_count && best_d2 && overflow_flag, "ac_nn_refine: null pointer");
   AC_REQUIRE(nk_rows > 0 && nq_rows > 0 && D > 0 && D % 32 == 0 && cap > 0, "ac_nn_refine: bad shape");
   AC_REQUIRE(D <= 32 * 64 * 4, "ac_nn_refine: D=%d above 8192", D);
@@ -573,12 +610,83 @@ extern "C" int ac_nn_refine(const void* Zk_hl32, int64_t nk_rows, const void* Zq
 #define AC_REFINE(G)                                                                                                   \
   hipLaunchKernelGGL(nn_refine_kernel<G>, grid, dim3(256), 0, as_stream(stream), static_cast<const uint8_t*>(Zk_hl32),   \
                      nk_rows, static_cast<const uint8_t*>(Zq_hl32), nq_rows, D, cand, cand_count, cap, key_row_offset,     \
-                     best_d2, overflow_flag)
+                     best_d2, overflow_flag, overflow_rows, slack)
   if (gpl <= 1) AC_REFINE(1);
   else if (gpl == 2) AC_REFINE(2);
   else AC_REFINE(4);
 #undef AC_REFINE
   return ac_check_launch("ac_nn_refine");
+}
+
+// The queries whose candidate list overflowed on some key set (overflow_rows[q] != 0), compacted on the device in
+// ascending order: one workgroup, every thread counts a contiguous chunk, one scan of the 1024 counts in LDS.
+__global__ __launch_bounds__(1024) void nn_overflow_compact_kernel(const int* __restrict__ rows, int64_t n, int* __restrict__ idx,
+                                                                   int* __restrict__ n_out) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024, lo = t * per, hi = (lo + per < n) ? lo + per : n;
+  int c = 0;
+  for (int64_t i = lo; i < hi; ++i) c += rows[i] != 0;
+  cnt[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                       // inclusive scan (Hillis-Steele)
+    const int v = (t >= o) ? cnt[t - o] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  int pos = cnt[t] - c;
+  for (int64_t i = lo; i < hi; ++i)
+    if (rows[i] != 0) idx[pos++] = (int)i;
+  if (t == 1023) n_out[0] = cnt[1023];
+}
+
+extern "C" int ac_nn_overflow_compact(const int32_t* overflow_rows, int64_t n, int32_t* idx, int32_t* n_out, void* stream) {
+  AC_REQUIRE(overflow_rows && idx && n_out, "ac_nn_overflow_compact: null pointer");
+  AC_REQUIRE(n >= 0 && n <= 0x7fffff00LL, "ac_nn_overflow_compact: n=%lld out of range", (long long)n);
+  hipLaunchKernelGGL(nn_overflow_compact_kernel, dim3(1), dim3(1024), 0, as_stream(stream), overflow_rows, n, idx, n_out);
+  return ac_check_launch("ac_nn_overflow_compact");
+}
+
+// dst row r = src row idx[min(r, n_idx - 1)], r < n_rows (rows beyond the list repeat its last row: padding of the
+// compact query copy to whole images).  One wave per row, 16-byte pieces when the row allows, dwords otherwise.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ src, int64_t row_bytes, const int* __restrict__ idx,
+                                                          int64_t n_idx, int64_t n_rows, uint8_t* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const uint8_t* s = src + (size_t)idx[r < n_idx ? r : n_idx - 1] * row_bytes;
+  uint8_t* d = dst + (size_t)r * row_bytes;
+  if ((row_bytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    for (int64_t o = (int64_t)lane * 16; o < row_bytes; o += 1024) *reinterpret_cast<u32x4*>(d + o) = *reinterpret_cast<const u32x4*>(s + o);
+  } else {
+    for (int64_t o = (int64_t)lane * 4; o < row_bytes; o += 256) *reinterpret_cast<uint32_t*>(d + o) = *reinterpret_cast<const uint32_t*>(s + o);
+  }
+}
+
+extern "C" int ac_gather_rows(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n_idx, int64_t n_rows, void* dst,
+                              void* stream) {
+  AC_REQUIRE(src && idx && dst, "ac_gather_rows: null pointer");
+  AC_REQUIRE(row_bytes > 0 && row_bytes % 4 == 0, "ac_gather_rows: row_bytes=%lld must be a positive multiple of 4", (long long)row_bytes);
+  AC_REQUIRE(n_idx > 0 && n_rows >= n_idx, "ac_gather_rows: n_idx=%lld n_rows=%lld", (long long)n_idx, (long long)n_rows);
+  AC_REQUIRE((n_rows + 3) / 4 <= 0x7fffffffLL, "ac_gather_rows: too many rows");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, as_stream(stream),
+                     static_cast<const uint8_t*>(src), row_bytes, idx, n_idx, n_rows, static_cast<uint8_t*>(dst));
+  return ac_check_launch("ac_gather_rows");
+}
+
+// best_d2[idx[i]] = the exhaustive kernel's min d2 of compact query i (uint32 float bits): those queries take the
+// exhaustive answer as it stands, so they equal the un-pruned path bit for bit.
+__global__ void nn_scatter_kernel(const unsigned* __restrict__ acc_bits, const int* __restrict__ idx, int64_t n, double* __restrict__ best) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) best[idx[i]] = (double)__uint_as_float(acc_bits[i]);
+}
+
+extern "C" int ac_nn_scatter_exhaustive(const uint32_t* acc_bits, const int32_t* idx, int64_t n, double* best_d2, void* stream) {
+  AC_REQUIRE(acc_bits && idx && best_d2, "ac_nn_scatter_exhaustive: null pointer");
+  if (n <= 0) return AC_OK;
+  hipLaunchKernelGGL(nn_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), acc_bits, idx, n, best_d2);
+  return ac_check_launch("ac_nn_scatter_exhaustive");
 }
 
 // ------------------------------------------------------------ alpha softmax

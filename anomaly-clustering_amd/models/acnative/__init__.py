@@ -50,6 +50,8 @@ SIGNATURES = {
     "ac_pair_min_dist_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
     "ac_pair_min_dist": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ac_fill_u32": (_i, [_vp, _i64, _c.c_uint32, _vp]),
+    "ac_fill_u64": (_i, [_vp, _i64, _c.c_uint64, _vp]),
     "ac_max_f32": (_i, [_vp, _i64, _vp, _vp]),
     "ac_pair_fixed_shift": (_i, [_vp, _i64, _vp, _vp]),
     "ac_pair_accumulate": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i64, _vp, _vp, _vp]),
@@ -57,7 +59,10 @@ SIGNATURES = {
     "ac_h16_from_hl32": (_i, [_vp, _i64, _i, _vp, _vp]),
     "ac_nn_slack": (_i, [_vp, _vp, _vp, _vp]),
     "ac_nn_candidates": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
-    "ac_nn_refine": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "ac_nn_refine": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "ac_nn_overflow_compact": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "ac_gather_rows": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "ac_nn_scatter_exhaustive": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "ac_nn_finalize": (_i, [_vp, _i64, _vp, _vp]),
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
@@ -326,6 +331,7 @@ def pair_min_dist(Zq, Zk, reduce, self_offset=0):
 kernel_events = None   # set to a list to collect (label, start, stop, ...) torch events around MFMA launches
 NO_SELF = -(1 << 62)   # self_first value that skips nothing in pair_accumulate
 INF_BITS = 0x7f800000
+F64_INF_BITS = 0x7ff0000000000000
 
 
 class Packed:
@@ -360,7 +366,7 @@ def pack_images(Z):
 
 def max_sq(packed_list, device):
     """Running max of the squared norms over several packed blocks: fp32 [1] on the device."""
-    out = torch.zeros(1, dtype=torch.float32, device=device)
+    out = filled((1,), torch.float32, device, 0)
     for pk in packed_list:
         if pk.n:
             _check(lib().ac_max_f32(pk.sq.data_ptr(), pk.sq.numel(), out.data_ptr(), _stream()))
@@ -374,11 +380,31 @@ def fixed_shift(max_sq_t, n_keys):
     return shift
 
 
+def fill_(t, bits=0):
+    """In place: every element of the contiguous device tensor t (4- or 8-byte elements) = the bit pattern `bits`,
+    written by the LIBRARY on the current stream (ac_fill_u32 / ac_fill_u64)."""
+    if t.numel():
+        _dev(t, None, "t")
+        if t.element_size() == 4:
+            _check(lib().ac_fill_u32(t.data_ptr(), t.numel(), bits, _stream()))
+        elif t.element_size() == 8:
+            _check(lib().ac_fill_u64(t.data_ptr(), t.numel(), bits, _stream()))
+        else:
+            raise TypeError("fill_: %s has neither 4- nor 8-byte elements" % t.dtype)
+    return t
+
+
+def filled(shape, dtype, device, bits=0):
+    """A new device tensor preset to a bit pattern by the library: +inf float bits for matrices of minima, 0 for
+    counters and int64 sums.  The engine's loops contain no torch kernels - only allocations."""
+    return fill_(torch.empty(shape, dtype=dtype, device=device), bits)
+
+
 def new_acc(ncols, reduce, device):
     """Accumulator of pair_accumulate: int64 zeros (mean) or uint32-as-int32 +inf bits (min)."""
     if reduce == REDUCE_MEAN_OTHERS:
-        return torch.zeros(ncols, dtype=torch.int64, device=device)
-    return torch.full((ncols,), INF_BITS, dtype=torch.int32, device=device)
+        return filled((ncols,), torch.int64, device, 0)
+    return filled((ncols,), torch.int32, device, INF_BITS)
 
 
 def _event_pair():
@@ -400,8 +426,8 @@ def pair_block(keys, queries, two_way=False, part=0, nparts=1):
     same = keys.hl.data_ptr() == queries.hl.data_ptr() and nk == nq
     if same and two_way:
         raise ValueError("keys == queries is the symmetric case, not a two-way block")
-    minbuf = torch.full((nk, nq * P), INF_BITS, dtype=torch.int32, device=dev)
-    minbuf_t = torch.full((nq, nk * P), INF_BITS, dtype=torch.int32, device=dev) if two_way else None
+    minbuf = filled((nk, nq * P), torch.int32, dev, INF_BITS)
+    minbuf_t = filled((nq, nk * P), torch.int32, dev, INF_BITS) if two_way else None
     ev0, ev1 = _event_pair()
     _check(lib().ac_pair_min_sq_packed(keys.hl.data_ptr(), keys.sq.data_ptr(), nk, queries.hl.data_ptr(),
                                        queries.sq.data_ptr(), nq, P, D, minbuf.data_ptr(),
@@ -509,31 +535,35 @@ def h16_from_packed(pk):
 
 
 def nn_slack(max_sq_keys, max_sq_queries):
-    s = torch.empty(2, dtype=torch.float32, device=max_sq_keys.device)
+    """fp32 [3] on the device: the candidate window (relative, absolute) and the fp16-range flag (include/ac_hip.h)."""
+    s = torch.empty(3, dtype=torch.float32, device=max_sq_keys.device)
     _check(lib().ac_nn_slack(_dev(max_sq_keys, torch.float32, "max_sq_keys"), _dev(max_sq_queries, torch.float32, "max_sq_queries"),
                              s.data_ptr(), _stream()))
     return s
 
 
 class NNState:
-    """Running state of one pruned search: per query row the approximate minimum, the exact minimum so far, and
-    the candidate list of the key set being scanned."""
+    """Running state of one pruned search: per query row the approximate minimum, the exact minimum so far, the
+    candidate list of the key set being scanned, and - sticky over the key sets - which queries had a list longer
+    than their slots (overflow_rows) and whether any had (overflow: the ONE word the host reads, once per search)."""
 
     def __init__(self, nq_rows, device, cap=NN_CAP):
         self.n, self.cap = nq_rows, cap
-        self.approx_min = torch.full((nq_rows,), INF_BITS, dtype=torch.int32, device=device)
-        self.best = torch.full((nq_rows,), float("inf"), dtype=torch.float64, device=device)
+        self.approx_min = filled((nq_rows,), torch.int32, device, INF_BITS)
+        self.best = filled((nq_rows,), torch.float64, device, F64_INF_BITS)
         self.cand = torch.empty((nq_rows, cap), dtype=torch.int32, device=device)
-        self.count = torch.zeros((nq_rows,), dtype=torch.int32, device=device)
-        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        self.count = filled((nq_rows,), torch.int32, device, 0)
+        self.overflow_rows = filled((nq_rows,), torch.int32, device, 0)
+        self.overflow = filled((1,), torch.int32, device, 0)
 
 
 def nn_scan(state, keys, keys_h16, queries, queries_h16, slack):
-    """One key set against all queries: pass 1 (candidates) + pass 2 (exact distances of the candidates)."""
+    """One key set against all queries: pass 1 (candidates) + pass 2 (exact distances of the candidates).  Nothing is
+    read back: a query whose list overflowed is marked in state.overflow_rows for nn_fix_overflow at the end."""
     if keys.n == 0 or queries.n == 0:
         return
     nk, nq, D = keys.n * keys.P, queries.n * queries.P, keys.D
-    state.count.zero_()
+    fill_(state.count, 0)
     ev0, ev1 = _event_pair()
     _check(lib().ac_nn_candidates(keys_h16.data_ptr(), keys.sq.data_ptr(), nk, queries_h16.data_ptr(), queries.sq.data_ptr(), nq, D,
                                   slack.data_ptr(), state.approx_min.data_ptr(), state.cand.data_ptr(), state.count.data_ptr(),
@@ -542,30 +572,49 @@ def nn_scan(state, keys, keys_h16, queries, queries_h16, slack):
         ev1.record()
         kernel_events.append(("nn_candidates", ev0, ev1, 1.0 * keys.n * queries.n, keys.P, D))
     _check(lib().ac_nn_refine(keys.hl.data_ptr(), nk, queries.hl.data_ptr(), nq, D, state.cand.data_ptr(), state.count.data_ptr(),
-                              state.cap, 0, state.best.data_ptr(), state.overflow.data_ptr(), _stream()))
+                              state.cap, 0, state.best.data_ptr(), state.overflow.data_ptr(), state.overflow_rows.data_ptr(),
+                              slack.data_ptr(), _stream()))
 
 
-def nn_fix_overflow(state, keys, queries, budget=1 << 30):
-    """Queries whose candidate list of this key set was longer than the slots (many bank patches within the error
-    bound of the nearest one - e.g. a uniform background): their exact minimum over the key set comes from the
-    exhaustive one-way split-fp16 kernel on a compact copy of just those rows.  Returns how many there were."""
-    over = state.count > state.cap
-    n_ovf = int(over.sum().item())
-    if n_ovf == 0:
-        return 0
-    idx = over.nonzero().flatten()
-    P, D = queries.P, queries.D
-    pad = (-n_ovf) % P                                   # the kernel's query axis comes in whole "images" of P rows
-    sel = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
-    Qc = Packed(queries.hl.index_select(0, sel).contiguous(), queries.sq.index_select(0, sel).contiguous(), sel.numel() // P, P, D)
-    acc = new_acc(sel.numel(), REDUCE_MIN_ALL, queries.hl.device)
-    c = max(1, int(budget // (4 * P * max(Qc.n, 1))))                 # key images per launch: minbuf [c, Qc.n * P] in the budget
-    for k0 in range(0, keys.n, c):
-        mb = pair_block(keys.slice(k0, min(keys.n, k0 + c)), Qc)
-        pair_accumulate(mb, P, REDUCE_MIN_ALL, NO_SELF, None, acc)
-    d2 = acc[:n_ovf].view(torch.float32).double()
-    state.best[idx] = torch.minimum(state.best[idx], d2)
-    return n_ovf
+class OverflowQueries:
+    """The overflowed query rows of a search as a compact Packed block (padded to whole images) + their row indices
+    + the uint32 min accumulator the exhaustive blocks fold into."""
+
+    def __init__(self, state, queries):
+        dev = queries.hl.device
+        P, D = queries.P, queries.D
+        self.idx = torch.empty((max(state.n, 1),), dtype=torch.int32, device=dev)
+        n_out = torch.empty(1, dtype=torch.int32, device=dev)
+        _check(lib().ac_nn_overflow_compact(state.overflow_rows.data_ptr(), state.n, self.idx.data_ptr(), n_out.data_ptr(), _stream()))
+        self.n_rows = int(n_out.item())                        # slow path: the host sizes the compact copy
+        self.packed = None
+        if self.n_rows:
+            rows = -(-self.n_rows // P) * P                    # the kernel's query axis comes in whole "images" of P rows
+            hl = torch.empty((rows, D * 4), dtype=torch.uint8, device=dev)
+            sq = torch.empty((rows,), dtype=torch.float32, device=dev)
+            _check(lib().ac_gather_rows(queries.hl.data_ptr(), D * 4, self.idx.data_ptr(), self.n_rows, rows, hl.data_ptr(), _stream()))
+            _check(lib().ac_gather_rows(queries.sq.data_ptr(), 4, self.idx.data_ptr(), self.n_rows, rows, sq.data_ptr(), _stream()))
+            self.packed = Packed(hl, sq, rows // P, P, D)
+            self.acc = new_acc(rows, REDUCE_MIN_ALL, dev)
+
+    def scan(self, keys, budget=1 << 30):
+        """Exhaustive one-way split-fp16 blocks: one key set against the compact queries."""
+        if not self.n_rows or keys is None or keys.n == 0:
+            return
+        Qc = self.packed
+        c = max(1, int(budget // (4 * Qc.P * max(Qc.n, 1))))   # key images per launch: minbuf [c, Qc.n * P] in the budget
+        for k0 in range(0, keys.n, c):
+            mb = pair_block(keys.slice(k0, min(keys.n, k0 + c)), Qc)
+            pair_accumulate(mb, Qc.P, REDUCE_MIN_ALL, NO_SELF, None, self.acc)
+
+    def commit(self, state):
+        if self.n_rows:
+            _check(lib().ac_nn_scatter_exhaustive(self.acc.data_ptr(), self.idx.data_ptr(), self.n_rows, state.best.data_ptr(), _stream()))
+
+
+def nn_any_overflow(state):
+    """The search's one host read: did any query overflow on any key set (or the norms leave the fp16 range)?"""
+    return bool(int(state.overflow.item()))
 
 
 def nn_finalize(state, P):

@@ -167,9 +167,14 @@ class HipOps:
     def nn_state(self, nq_rows, device):
         return self.acnative.NNState(nq_rows, device, self.nn_cap or self.acnative.NN_CAP)
 
-    def nn_scan(self, state, keys, keys_h16, queries, queries_h16, slack, budget=MINBUF_BYTES):
-        self.acnative.nn_scan(state, keys, keys_h16, queries, queries_h16, slack)
-        return self.acnative.nn_fix_overflow(state, keys, queries, budget)      # queries with too many near-ties
+    def nn_scan(self, state, keys, keys_h16, queries, queries_h16, slack):
+        self.acnative.nn_scan(state, keys, keys_h16, queries, queries_h16, slack)        # nothing is read back
+
+    def nn_any_overflow(self, state):
+        return self.acnative.nn_any_overflow(state)                                      # the search's one host read
+
+    def nn_overflow_queries(self, state, queries):
+        return self.acnative.OverflowQueries(state, queries)
 
     def nn_finalize(self, state, P):
         return self.acnative.nn_finalize(state, P)
@@ -241,7 +246,9 @@ class _Ring:
         self.ops, self.local, self.sizes, self.rank, self.world, self.group = ops, local, sizes, rank, world, group
         self.cap = max(sizes) if sizes else 0
         self.last = last_step
-        per_buffer = max(1, sum(t[:1].numel() * t.element_size() for t in local.tensors()) * local.P * self.cap)
+        # bytes of one receive buffer from the SHAPE (hl32 row + its norm), not from the local tensors: a rank with an
+        # empty shard must arrive at the same depth as the others
+        per_buffer = max(1, (local.D * 4 + 4) * local.P * self.cap)
         self.depth = max(2, min(max(last_step, 1), remote_bytes // per_buffer))
         self.bufs = [None] * self.depth
         self.pending = {}
@@ -373,29 +380,26 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
         state = ops.nn_state(n_loc * P, device)
         q16 = ops.h16(pk_loc)
         ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
-        exhaustive_acc = None                       # set once pruning has proved useless on this data (see below)
-        c = block_images(P, budget)
-        for k in range(world):
+        for k in range(world):                      # the whole ring is queued without a host read
             keys = pk_bank_loc if k == 0 else ring.get(k)
             if keys is None or keys.n == 0 or n_loc == 0:
                 continue
-            if exhaustive_acc is None:
-                n_ovf = ops.nn_scan(state, keys, ops.h16(keys), pk_loc, q16, slack, budget)
-                # More than half of the query patches had more near-ties than candidate slots (e.g. a bank of
-                # near-identical images): the first pass buys nothing here, so the remaining shards go straight
-                # to the exhaustive blocks - the regression against prune=False is bounded by this one pass.
-                if 2 * n_ovf > n_loc * P:
-                    exhaustive_acc = ops.new_acc(n_loc * P, MIN, device)
-            else:
-                for q0, q1 in _subranges(0, n_loc, c):
-                    Q = pk_loc.slice(q0, q1)
-                    for k0, k1 in _subranges(0, keys.n, c):
-                        mb = ops.pair_block(keys.slice(k0, k1), Q)
-                        ops.pair_accumulate(mb, P, MIN, NO_SELF, None, exhaustive_acc[q0 * P: q1 * P])
-        w = ops.nn_finalize(state, P)
-        if exhaustive_acc is not None:
-            w = torch.minimum(w, ops.pair_finalize(exhaustive_acc, P, MIN, m, None))
-        return w
+            ops.nn_scan(state, keys, ops.h16(keys), pk_loc, q16, slack)
+        # ONE host read per search: did any query patch, on any bank shard, have more near-ties than candidate slots
+        # (e.g. a uniform background against a bank of the same background)?  On ordinary data: no, and this is
+        # all.  Otherwise those queries - on every rank, hence the MAX all-reduce of the flag: the ring is collective
+        # - meet the whole bank again through the exhaustive one-way split-fp16 blocks, on a compact copy, and take
+        # that answer as it stands (bit-equal to prune=False).  A bank on which every query overflows therefore costs
+        # one wasted first pass (a third of the exhaustive work) - the bound of the regression against prune=False.
+        if world > 1:
+            dist.all_reduce(state.overflow, op=dist.ReduceOp.MAX, group=group)
+        if ops.nn_any_overflow(state):
+            over = ops.nn_overflow_queries(state, pk_loc)
+            ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
+            for k in range(world):
+                over.scan(pk_bank_loc if k == 0 else ring.get(k), budget)
+            over.commit(state)
+        return ops.nn_finalize(state, P)
     acc = ops.new_acc(n_loc * P, MIN, device)
     ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
     c = block_images(P, budget)

@@ -167,7 +167,7 @@ int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, i
  *       keys (nk images) x queries (nq images):
  *         minbuf[j][i*P + p]   = min(minbuf[..],   min_q d2(Zq[i][p], Zk[j][q]))     uint32 [nk][nq*P]
  *         minbuf_t[i][j*P + q] = min(minbuf_t[..], min_p d2(Zq[i][p], Zk[j][q]))     uint32 [nq][nk*P]
- *       as the IEEE bits of a non-negative float; the caller presets them to +inf (0x7f800000).
+ *       as the IEEE bits of a non-negative float; the caller presets them to +inf (0x7f800000) with ac_fill_u32.
  *       - minbuf_t == NULL: one direction only (supervised: test patches against the normal bank).
  *       - minbuf_t != NULL ("two-way"): the block between two DIFFERENT image sets of one unsupervised
  *         category is reduced in both directions from a single pass over its tiles, so a category costs
@@ -193,6 +193,8 @@ int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, i
 int ac_pair_min_sq_packed(const void* Zk_hl32, const float* k_sqnorm, int64_t nk, const void* Zq_hl32,
                           const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, uint32_t* minbuf_t,
                           int part, int nparts, void* stream);
+int ac_fill_u32(uint32_t* dst, int64_t count, uint32_t value, void* stream);   /* presets: +inf bits 0x7f800000, zeros */
+int ac_fill_u64(uint64_t* dst, int64_t count, uint64_t value, void* stream);   /* int64 sums (0), float64 +inf bits */
 int ac_max_f32(const float* x, int64_t n, float* max_out, void* stream);
 int ac_pair_fixed_shift(const float* max_sq, int64_t n_keys, int32_t* shift, void* stream);
 int ac_pair_accumulate(const uint32_t* minbuf, int64_t nk, int64_t ld, int64_t ncols, int P, int reduce,
@@ -203,17 +205,29 @@ int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, 
 /* Supervised weights as an EXACT pruned nearest-neighbour search (utils.py:230-237: the min runs over every patch of
  * the normal-image bank, so only the nearest bank patch of each query patch needs an exact distance):
  *   ac_h16_from_hl32: the hi plane of an hl32 image as plain fp16 rows [rows][K] (K % 64 == 0).
- *   ac_nn_slack:      slack (device float [2]): the candidate window of a query a is slack[0] * |a| + slack[1] = 2 delta(a),
+ *   ac_nn_slack:      slack (device float [3]): the candidate window of a query a is slack[0] * |a| + slack[1] = 2 delta(a),
  *                     delta(a) = the bound on |d~2 - d2| of pass 1 for that query, from the largest squared norms of
- *                     the two sets (ac_max_f32).
+ *                     the two sets (ac_max_f32).  slack[2] != 0: a norm is outside the range in which the fp16 high
+ *                     halves are finite (|row| >= 65504, inf or NaN) - pass 1 proves nothing there, and ac_nn_refine
+ *                     then treats EVERY query as overflowed (below), so the exhaustive kernel decides.
  *   ac_nn_candidates: pass 1, one MFMA launch on the fp16 hi planes (a third of the 3-pass work, half the bytes):
  *                     keeps the running minimum approx_min[q] of d~2 over all launches (uint32 float bits, preset
  *                     +inf) and appends to cand[q][.] every key row with d~2 <= running minimum + slack; cand_count
  *                     [q] counts them (the caller zeroes it per key set; rows beyond `cap` are counted, not stored).
  *   ac_nn_refine:     pass 2: best_d2[q] = min(best_d2[q], sum_k (q_k - key_k)^2) in fp64 on the split values of the
  *                     hl32 images, over the stored candidates.  A query whose list was longer than cap
- *                     (cand_count[q] > cap) is SKIPPED and overflow_flag (int32 [1]) set: the caller measures those
- *                     queries against this key set with the exhaustive kernel (ac_pair_min_sq_packed, one-way).
+ *                     (cand_count[q] > cap) is SKIPPED, overflow_flag (int32 [1]) set and overflow_rows[q] (int32
+ *                     [nq_rows], may be NULL; sticky across key sets, the caller zeroes it once per search) set: the
+ *                     caller measures those queries against the WHOLE bank with the exhaustive kernel
+ *                     (ac_pair_min_sq_packed, one-way) - nothing is read back per key set; one read of overflow_flag
+ *                     at the end of the search says whether any of this is needed.  slack: ac_nn_slack's vector (may
+ *                     be NULL = no range check).
+ *   ac_nn_overflow_compact: idx (int32 [<= n]) = the q with overflow_rows[q] != 0 in ascending order, n_out[0] their
+ *                     number - on the device (one workgroup).
+ *   ac_gather_rows:   dst row r = src row idx[min(r, n_idx - 1)] for r < n_rows (row_bytes % 4 == 0): the compact
+ *                     copy of the overflowed queries (hl32 rows and squared norms), padded to whole images.
+ *   ac_nn_scatter_exhaustive: best_d2[idx[i]] = (double) of the exhaustive kernel's min d2 (uint32 float bits) of
+ *                     compact query i: those queries equal the un-pruned path bit for bit.
  *   ac_nn_finalize:   w = (float)sqrt(best_d2).
  * The true nearest neighbour always survives pass 1 (proof in csrc/alpha.hip), whatever the order of the tiles. */
 int ac_h16_from_hl32(const void* hl32, int64_t rows, int K, void* dst_h16, void* stream);
@@ -223,7 +237,11 @@ int ac_nn_candidates(const void* Zk_h16, const float* k_sq, int64_t nk_rows, con
                      int cap, int64_t key_row_offset, void* stream);
 int ac_nn_refine(const void* Zk_hl32, int64_t nk_rows, const void* Zq_hl32, int64_t nq_rows, int D, const int32_t* cand,
                  const int32_t* cand_count, int cap, int64_t key_row_offset, double* best_d2, int32_t* overflow_flag,
-                 void* stream);
+                 int32_t* overflow_rows, const float* slack, void* stream);
+int ac_nn_overflow_compact(const int32_t* overflow_rows, int64_t n, int32_t* idx, int32_t* n_out, void* stream);
+int ac_gather_rows(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n_idx, int64_t n_rows, void* dst,
+                   void* stream);
+int ac_nn_scatter_exhaustive(const uint32_t* acc_bits, const int32_t* idx, int64_t n, double* best_d2, void* stream);
 int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream);
 
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:

@@ -268,6 +268,30 @@ def test_pruned_search_re_measures_queries_whose_candidate_lists_overflow(dev):
     assert (got - ref).abs().max().item() <= 2e-5
 
 
+def test_pruned_search_leaves_norms_beyond_fp16_to_the_exhaustive_kernel(dev):
+    """The error bound of the first pass needs finite fp16 high halves, which |row| < 65504 guarantees.  Rows with a
+    larger norm (here every element is still inside fp16's range: D = 256 values of ~5000 give |row| ~ 80 000) flip
+    ac_nn_slack's range flag: every query is treated as overflowed and the exhaustive split-fp16 blocks decide - the
+    answer is prune=False's, bit for bit, and finite (the pruned path used to return silently wrong
+    minima once a high half became inf)."""
+    import acnative
+    from patchcore.pipeline import run_category
+    Zq, _ = clustered_embeddings(3, 100, 256, 2, salt=85)
+    Zk, _ = clustered_embeddings(4, 100, 256, 1, salt=86)
+    tq, tk = torch.from_numpy(Zq * 8000.0).to(dev), torch.from_numpy(Zk * 8000.0).to(dev)
+    pk = acnative.pack_images(tk)
+    assert float(acnative.max_sq([pk], dev).sqrt().item()) > 65504.0 and float(tk.abs().max().item()) < 65504.0
+    s = acnative.nn_slack(acnative.max_sq([pk], dev), acnative.max_sq([acnative.pack_images(tq)], dev))
+    assert float(s[2].item()) == 1.0
+    pruned = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0)["w_loc"]
+    exhaustive = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0, prune=False)["w_loc"]
+    assert torch.isfinite(pruned).all() and torch.equal(pruned, exhaustive)
+    # in range: the flag stays clear
+    s = acnative.nn_slack(acnative.max_sq([acnative.pack_images(torch.from_numpy(Zk).to(dev))], dev),
+                          acnative.max_sq([acnative.pack_images(torch.from_numpy(Zq).to(dev))], dev))
+    assert float(s[2].item()) == 0.0
+
+
 def test_fixed_point_scale_follows_the_data(dev):
     """The shift of the 64-bit fixed-point sum comes from n_keys * 2 sqrt(max |z|^2): capped at 40 for ordinary
     data, lower when many keys or large norms would overflow 2^62 - and w barely notices (resolution 2^-shift)."""
