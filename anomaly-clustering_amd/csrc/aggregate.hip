@@ -131,10 +131,11 @@ __global__ __launch_bounds__(256) void agg_pool_kernel(AggParams prm) {
     auto val = [&](int c, int yy, int xx) -> float {
       if (yy < 0 || yy >= L.H || xx < 0 || xx >= L.W) return 0.f;
       size_t idx = (L.kind == AC_FEAT_TOKENS) ? ((size_t)b * (HW + 1) + 1 + yy * L.W + xx) * L.C + c
+                   : (L.kind == AC_FEAT_NHWC) ? ((size_t)b * HW + yy * L.W + xx) * L.C + c
                                               : (((size_t)b * L.C + c) * L.H + yy) * L.W + xx;
       return (L.f[idx] - mean) * rstd;
     };
-    if (L.kind == AC_FEAT_TOKENS) {
+    if (L.kind != AC_FEAT_NCHW) {
       // channel on the thread: global reads contiguous in c; LDS writes at stride k2 floats
       for (int kk = 0; kk < k2; ++kk) {
         const int dy = kk / k - pad, dx = kk - (kk / k) * k - pad;
@@ -333,7 +334,8 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
   int maxL = 0;
   for (int l = 0; l < n_layers; ++l) {
     AC_REQUIRE(feats[l] && C[l] > 0 && H[l] > 0 && W[l] > 0, "ac_patch_aggregate: bad layer %d", l);
-    AC_REQUIRE(kind[l] == AC_FEAT_TOKENS || kind[l] == AC_FEAT_NCHW, "ac_patch_aggregate: bad kind for layer %d", l);
+    AC_REQUIRE(kind[l] == AC_FEAT_TOKENS || kind[l] == AC_FEAT_NCHW || kind[l] == AC_FEAT_NHWC,
+               "ac_patch_aggregate: bad kind for layer %d", l);
     prm.layer[l] = AggLayer{feats[l], norm + (size_t)l * B * 2, kind[l], C[l], H[l], W[l]};
     maxL = maxL > C[l] * patchsize * patchsize ? maxL : C[l] * patchsize * patchsize;
     size_t n = (size_t)C[l] * H[l] * W[l];

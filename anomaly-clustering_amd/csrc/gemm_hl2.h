@@ -47,6 +47,14 @@ constexpr int FLUSH_STAGES = 16;
 #ifndef AC_ABLATE
 #define AC_ABLATE 0
 #endif
+// Wave priority of the two half-stages (same-box A/B knobs, scratch/ab_pairmin.py; round-3 result in DESIGN.md
+// section 4): P2 = the 48-MFMA segment, P1 = fragment reads + DMA issue of the partner wave.
+#ifndef AC_G2_P2PRIO
+#define AC_G2_P2PRIO 1
+#endif
+#ifndef AC_G2_P1PRIO
+#define AC_G2_P1PRIO 0
+#endif
 
 // Diagnostic build -DAC_TILE_TIMING: every workgroup records 100 MHz timestamps (entry, first stage
 // visible, k loop done, epilogue stores done) into a per-TU buffer; the `stagger` argument then carries
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- P2(kt)
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(AC_G2_P2PRIO);
       if (!(AC_ABLATE & 4))
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
             f.acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], f.acc[mi][ni], 0, 0, 0);
           }
         }
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(AC_G2_P1PRIO);
       // Two-level accumulation (see gemm_hl.h): flush the MFMA accumulator every 512 k-terms.
       if (FLUSH && (kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
 #pragma unroll

@@ -19,6 +19,7 @@ REDUCE_MEAN_OTHERS = 0
 REDUCE_MIN_ALL = 1
 FEAT_TOKENS = 0
 FEAT_NCHW = 1
+FEAT_NHWC = 2
 
 _c = ctypes
 _vp, _i, _i64, _sz, _f, _d = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_size_t, _c.c_float, _c.c_double
@@ -42,6 +43,9 @@ SIGNATURES = {
     "ac_vit_prepare_tokens": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ac_vit_block": (_i, [_c.POINTER(BlockWeights), _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ac_layernorm_rows": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp]),
+    "ac_im2col_hl32": (_i, [_vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ac_conv_gemm_bn": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "ac_maxpool_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ac_patch_aggregate_workspace_bytes": (_sz, [_i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _i, _i]),
     "ac_patch_aggregate": (_i, [_c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i),
                                 _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
@@ -255,17 +259,60 @@ def layernorm_rows(x, norm):
     return y
 
 
+# ------------------------------------------------------ convolutional layers
+def im2col_hl32(x_nhwc, kh, kw, stride, pad, Kpad):
+    """x: fp32 device tensor indexed [B, H, W, C] with ANY strides (NHWC activations, or the permuted view of the NCHW
+    image) -> hl32 uint8 [B*Ho*Wo, Kpad*4], column k = (ky*kw + kx)*C + c (include/ac_hip.h)."""
+    if not isinstance(x_nhwc, torch.Tensor) or not x_nhwc.is_cuda or x_nhwc.dtype != torch.float32 or x_nhwc.dim() != 4:
+        raise RuntimeError("im2col_hl32 needs an fp32 [B, H, W, C] tensor on the HIP device; there is no CPU fallback")
+    B, H, W, C = x_nhwc.shape
+    sb, sy, sx, sc = x_nhwc.stride()
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = torch.empty((B * Ho * Wo, Kpad * 4), dtype=torch.uint8, device=x_nhwc.device)
+    _check(lib().ac_im2col_hl32(x_nhwc.data_ptr(), B, C, H, W, sb, sc, sy, sx, kh, kw, stride, pad, Kpad, out.data_ptr(), _stream()))
+    return out
+
+
+def conv_gemm_bn(A_hl, W_hl, M, N, K, alpha, beta, res, relu):
+    """fp32 [M, N] = relu?((A . W^T) * alpha + beta (+ res)): convolution as a GEMM + eval BatchNorm + residual + ReLU."""
+    out = torch.empty((M, N), dtype=torch.float32, device=A_hl.device)
+    if A_hl.numel() != M * K * 4 or W_hl.numel() != N * K * 4:
+        raise ValueError("operand sizes do not match M=%d N=%d K=%d" % (M, N, K))
+    _check(lib().ac_conv_gemm_bn(_dev(A_hl, torch.uint8, "A"), _dev(W_hl, torch.uint8, "W"), M, N, K,
+                                 _dev(alpha, torch.float32, "alpha"), _dev(beta, torch.float32, "beta"),
+                                 _dev(res, torch.float32, "res") if res is not None else None, int(bool(relu)),
+                                 out.data_ptr(), _stream()))
+    return out
+
+
+def maxpool_nhwc(x, k, stride, pad):
+    """nn.MaxPool2d(k, stride, pad) on a contiguous fp32 [B, H, W, C] device tensor."""
+    p = _dev(x, torch.float32, "x")
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    _check(lib().ac_maxpool_nhwc(p, B, H, W, C, k, stride, pad, out.data_ptr(), _stream()))
+    return out
+
+
 # --------------------------------------------------------- patch aggregation
 def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5, out=None):
     """features: list of fp32 device tensors, each [B, T, C] (token map with CLS) or [B, C, H, W].
     Returns Z fp32 [B * H0 * W0, tgt_dim] (written into `out` when given) and the per-layer patch grids."""
     n = len(features)
-    feats = [f.to(torch.float32).contiguous() for f in features]
+    feats, nhwc = [], []
+    for f in features:
+        # a [B, C, H, W] tensor in channels-last memory (what the HIP CNN layers write) is read in place
+        cl = f.dim() == 4 and f.dtype == torch.float32 and not f.is_contiguous() and f.permute(0, 2, 3, 1).is_contiguous()
+        nhwc.append(cl)
+        feats.append(f.permute(0, 2, 3, 1) if cl else f.to(torch.float32).contiguous())
     ptrs = (_vp * n)(*[_dev(f, torch.float32, "feature") for f in feats])
     kinds, Cs, Hs, Ws = (_i * n)(), (_i * n)(), (_i * n)(), (_i * n)()
     B = feats[0].shape[0]
     for j, f in enumerate(feats):
-        if f.dim() == 3:
+        if nhwc[j]:
+            kinds[j], Cs[j], Hs[j], Ws[j] = FEAT_NHWC, f.shape[3], f.shape[1], f.shape[2]
+        elif f.dim() == 3:
             side = int(round((f.shape[1] - 1) ** 0.5))
             if side * side + 1 != f.shape[1]:
                 raise ValueError("token map with %d tokens is not CLS + square grid" % f.shape[1])

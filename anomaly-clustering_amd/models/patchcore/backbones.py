@@ -13,10 +13,11 @@ here (no network) the weights come from
      string next to its artefacts.
   With neither, load() raises: clustering with random weights must never look like a real run.
 
-``wideresnet50`` (BASELINE config 1, reference backbones.py:27) needs torchvision for the real network; when
-torchvision is absent and ``$AC_BACKBONE_SEED`` is set, a seeded WRN50-SHAPED stand-in is returned
-(patchcore/standin_cnn.py: layer2 [512,28,28], layer3 [1024,14,14]) - torch convolutions, plumbing for the
-CPU/CLI path of config 1, NOT part of the MI355X hot path.  The other torchvision/timm names raise.
+``wideresnet50`` (BASELINE config 1, reference backbones.py:27: ``models.wide_resnet50_2(pretrained=True)``) is
+patchcore/wide_resnet.py: torchvision's published architecture under torchvision's module names, its forward on
+the MI355X (convolutions as split-fp16 MFMA GEMMs, csrc/cnn.hip).  Weights: ``$AC_WRN50_WEIGHTS`` (torchvision's
+``wide_resnet50_2-*.pth`` state_dict, file or directory, ``strict=True``), or - opt-in, as above - torchvision's own
+initialisation from ``$AC_BACKBONE_SEED``.  The other torchvision/timm names raise.
 """
 import os
 import sys
@@ -47,23 +48,48 @@ def _seed_opt_in(name):
     seed = os.environ.get("AC_BACKBONE_SEED")
     if seed is None:
         raise RuntimeError(
-            "no weights for backbone %r: set AC_DINO_WEIGHTS to a DINO checkpoint (file or directory), or opt in "
+            "no weights for backbone %r: set AC_DINO_WEIGHTS (DINO names) / AC_WRN50_WEIGHTS (wideresnet50) to a "
+            "checkpoint (file or directory), or opt in "
             "to the seeded random initialisation with AC_BACKBONE_SEED=<int> (benchmarks / parity tests only)" % name)
     return int(seed)
 
 
+_WRN50_FILE = "wide_resnet50_2-95faca4d.pth"      # torchvision's IMAGENET1K_V1 checkpoint (pretrained=True)
+
+
+def _load_wrn50(name):
+    from patchcore import wide_resnet
+    root = os.environ.get("AC_WRN50_WEIGHTS")
+    path = None
+    if root:
+        path = root if os.path.isfile(root) else os.path.join(root, _WRN50_FILE)
+        if not os.path.isfile(path):
+            raise FileNotFoundError("AC_WRN50_WEIGHTS=%r is set but %r was not found there" % (root, _WRN50_FILE))
+    source = path
+    if path is None:
+        seed = _seed_opt_in(name)
+        torch.manual_seed(seed)
+        source = "random-init(seed=%d)" % seed
+        print("WARNING: backbone %r runs on SEEDED RANDOM weights (%s), not torchvision's checkpoint" % (name, source),
+              file=sys.stderr)
+    model = wide_resnet.wide_resnet50_2()
+    for p in model.parameters():
+        p.requires_grad = False
+    model.eval()
+    if path is not None:
+        model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True), strict=True)
+    model.weights_source = source
+    if torch.cuda.is_available():
+        model.to(torch.device("cuda"))
+    return model
+
+
 def load(name):
     if name == "wideresnet50":
-        from patchcore import standin_cnn
-        seed = _seed_opt_in(name)
-        print("WARNING: backbone %r is a seeded WRN50-SHAPED stand-in (seed %d), not torchvision's pretrained "
-              "wide_resnet50_2: plumbing only" % (name, seed), file=sys.stderr)
-        model = standin_cnn.wrn50_shaped(seed)
-        model.weights_source = "standin-random-init(seed=%d)" % seed
-        return model
+        return _load_wrn50(name)
     if name not in _DINO:
         raise NotImplementedError(
-            "backbone %r is outside the MI355X hot path (only %s + the wideresnet50 stand-in); torchvision/timm "
+            "backbone %r is outside the MI355X hot path (only %s + wideresnet50); the other torchvision/timm "
             "backbones need those packages and a weight download" % (name, sorted(_DINO)))
     filename, patch_size = _DINO[name]
     path = _find_weights(filename)

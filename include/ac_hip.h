@@ -111,10 +111,33 @@ int ac_vit_block(const ac_block_weights* w /* host struct of device pointers */,
 int ac_layernorm_rows(const float* x, int64_t rows, int C, const float* w, const float* b, float eps,
                       float* y, void* stream);
 
+/* ------------------------------------------------------- convolutional layers */
+
+/* The layers of torchvision's wide_resnet50_2 up to layer3 - the reference's `wideresnet50` backbone
+ * (models/patchcore/backbones.py:27: models.wide_resnet50_2(pretrained=True), tapped at layer2 / layer3 through
+ * models/patchcore/common.py:211-292) - as GEMMs on the split-fp16 MFMA engine.  Activations: NHWC fp32.
+ *
+ *   ac_im2col_hl32: x fp32 with ELEMENT strides (sb, sc, sy, sx) - NHWC activations (sc = 1) or the NCHW image -
+ *       -> hl32 [B*Ho*Wo, Kpad], column k = (ky*kw + kx)*C + c, zero beyond kh*kw*C and outside the image
+ *       (nn.Conv2d's zero padding `pad`); Ho = (H + 2 pad - kh) / stride + 1.  A 1x1 stride-1 convolution's
+ *       operand is simply ac_pack_hl32 of the activation.
+ *   ac_conv_gemm_bn: out[m][n] = relu?( (sum_k A[m][k] W[n][k]) * alpha[n] + beta[n] (+ res[m][n]) ), fp32 [M, N]:
+ *       nn.Conv2d(bias=False) + eval-mode nn.BatchNorm2d as torch's CPU kernel evaluates it
+ *       (alpha = weight / sqrt(running_var + eps), beta = bias - running_mean * alpha) + the Bottleneck's residual
+ *       and ReLU.  W: hl32 [N, K] = the conv weight permuted to [Cout, kh, kw, Cin] and flattened (zero padded to K).
+ *       N % 8 == 0, K % 32 == 0.  res may be NULL; out may alias res.
+ *   ac_maxpool_nhwc: nn.MaxPool2d(k, stride, pad) on NHWC fp32, C % 4 == 0. */
+int ac_im2col_hl32(const float* x, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int kh,
+                   int kw, int stride, int pad, int Kpad, void* out_hl32, void* stream);
+int ac_conv_gemm_bn(const void* A_hl32, const void* W_hl32, int64_t M, int N, int K, const float* alpha,
+                    const float* beta, const float* res, int relu, float* out, void* stream);
+int ac_maxpool_nhwc(const float* x, int B, int H, int W, int C, int k, int stride, int pad, float* out, void* stream);
+
 /* --------------------------------------------------------- patch aggregation */
 
 #define AC_FEAT_TOKENS 0 /* [B, 1+H*W, C] token map, CLS first (ViT) */
 #define AC_FEAT_NCHW 1   /* [B, C, H, W] (CNN backbones) */
+#define AC_FEAT_NHWC 2   /* [B, H, W, C]: the same map in channels-last memory (what the HIP CNN layers write) */
 
 size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C, const int* H, const int* W, int B,
                                           int patchsize, int pre_dim, int tgt_dim);

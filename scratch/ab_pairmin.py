@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Same-box, same-process A/B of builds of libac_hip.so on the all-pairs kernel (and optionally a ViT block).
+
+    python scratch/ab_pairmin.py [--n 83] [--rounds 5] name=path/to/lib.so name2=path2 ...
+
+Every library is loaded with ctypes side by side; the symmetric all-pairs launch (ac_pair_min_sq_packed on the
+same packed random Z, N images x 784 patches x 4096) runs `rounds` interleaved rounds per library; prints the
+median / min launch time per library and whether the minima are bit-equal to the first library's."""
+import argparse
+import ctypes as c
+import statistics
+import sys
+
+import torch
+
+P, D = 784, 4096
+INF = 0x7f800000
+
+
+def bind(path):
+    lib = c.CDLL(path)
+    vp, i64, i = c.c_void_p, c.c_int64, c.c_int
+    lib.ac_pack_hl32.argtypes = [vp, i64, i, i64, vp, vp, vp]
+    lib.ac_fill_u32.argtypes = [vp, i64, c.c_uint32, vp]
+    lib.ac_pair_min_sq_packed.argtypes = [vp, vp, i64, vp, vp, i64, i, i, vp, vp, i, i, vp]
+    lib.ac_last_error.restype = c.c_char_p
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=83)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    libs = [(s.split("=", 1)[0], bind(s.split("=", 1)[1])) for s in a.libs]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Z = (torch.randn((a.n, P, D), generator=g) * 0.6).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    hl = torch.empty((a.n * P, D * 4), dtype=torch.uint8, device=dev)
+    sq = torch.empty((a.n * P,), dtype=torch.float32, device=dev)
+    assert libs[0][1].ac_pack_hl32(Z.data_ptr(), a.n * P, D, D, hl.data_ptr(), sq.data_ptr(), st) == 0
+    mb = torch.empty((a.n, a.n * P), dtype=torch.int32, device=dev)
+    times = {name: [] for name, _ in libs}
+    ref = None
+    same = {}
+    for r in range(a.rounds + 1):                      # round 0 = warm-up
+        for name, lib in libs:
+            assert lib.ac_fill_u32(mb.data_ptr(), mb.numel(), INF, st) == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.ac_pair_min_sq_packed(hl.data_ptr(), sq.data_ptr(), a.n, hl.data_ptr(), sq.data_ptr(), a.n, P, D,
+                                           mb.data_ptr(), None, 0, 1, st)
+            e1.record()
+            assert rc == 0, lib.ac_last_error()
+            torch.cuda.synchronize()
+            if r:
+                times[name].append(e0.elapsed_time(e1))
+            else:
+                if ref is None:
+                    ref = mb.clone()
+                same[name] = bool(torch.equal(mb, ref))
+    flop = a.n * (a.n - 1.0) * 2 * P * P * D
+    for name, _ in libs:
+        t = times[name]
+        print("%-12s median %.3f ms  min %.3f  max %.3f  (%.0f TFLOP/s algorithmic at the median)  bit-equal to %s: %s"
+              % (name, statistics.median(t), min(t), max(t), flop / statistics.median(t) / 1e9, libs[0][0], same[name]))
+    # vendor reference on the same box: fp16 GEMM through torch (hipBLASLt / rocBLAS), random operands
+    for (m, n, k) in [(8192, 8192, 8192), (32768, 32768, 4096)]:
+        A = torch.randn((m, k), device=dev, dtype=torch.float16)
+        B = torch.randn((n, k), device=dev, dtype=torch.float16)
+        C = A @ B.T
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            C = A @ B.T
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        print("torch fp16 matmul %dx%dx%d (vendor library, random operands): median %.3f ms = %.0f TFLOP/s"
+              % (m, n, k, statistics.median(ts), 2.0 * m * n * k / statistics.median(ts) / 1e9))
+        del A, B, C
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,10 +1,10 @@
 """GPU: BASELINE config 1 through the CLI modules - "screw"-shaped tiny subset (first 4 images per class, N = 24),
-WideResNet50-SHAPED backbone (layer2 [512,28,28] + layer3 [1024,14,14]: the seeded stand-in of
-patchcore/standin_cnn.py, since torchvision and its checkpoint are absent), 1024 -> 1024, patchsize 3,
-`average` weights: examples/main.py -> pickle -> examples/test.py against the oracle on the same feature maps.
-Exercises the CNN branch of the aggregation kernel (bilinear alignment of the 14x14 patch grid to 28x28) and
-the artefact / CSV plumbing; the convolutions themselves are torch (MIOpen) and off the hot path, so the
-tolerance on X covers their fp32 reordering against the CPU convolutions (1e-4 absolute on values of O(0.3))."""
+WideResNet50 backbone (torchvision's wide_resnet50_2 architecture on the MI355X, patchcore/wide_resnet.py; seeded
+torchvision initialisation since the checkpoint is unreachable), layer2 [512,28,28] + layer3 [1024,14,14],
+1024 -> 1024, patchsize 3, `average` weights: examples/main.py -> pickle -> examples/test.py against the oracle
+(oracle/wrn.py taps -> oracle aggregation -> weighted average -> clustering) on the same images and weights.
+Exercises the HIP convolution path, the CNN branch of the aggregation kernel (bilinear alignment of the 14x14 patch
+grid to 28x28, channels-last maps read in place) and the artefact / CSV plumbing."""
 import numpy as np
 import pytest
 import torch
@@ -25,7 +25,7 @@ def test_config1_screw_subset_average(tmp_path, dev, monkeypatch):
     monkeypatch.setattr(synthetic, "SyntheticMVTecDataset", lambda **kw: orig(limit_per_class=4, **kw))
     monkeypatch.setenv("AC_BACKBONE_SEED", "5")
     backbone = patchcore.backbones.load("wideresnet50")
-    assert backbone.weights_source == "standin-random-init(seed=5)"
+    assert backbone.weights_source == "random-init(seed=5)"
     out = str(tmp_path / "outputs")
     layers = ["layer2", "layer3"]
     alpha, X = main.make_category_data(
@@ -38,9 +38,9 @@ def test_config1_screw_subset_average(tmp_path, dev, monkeypatch):
 
     ds = orig(classname="screw", split=synthetic.DatasetSplit.TEST, limit_per_class=4)
     assert len(ds) == 24
-    cpu_model = patchcore.backbones.load("wideresnet50")                    # same seed -> same weights, on the CPU
-    agg = common.NetworkFeatureAggregator(cpu_model, layers, torch.device("cpu"))
-    feats = agg(ds.images)
+    from oracle import wrn as owrn
+    sd = {k: v.detach().cpu() for k, v in backbone.state_dict().items()}
+    feats = owrn.forward_taps(sd, ds.images)
     Z = oagg.aggregate([feats["layer2"], feats["layer3"]], 3, 1024, 1024)[0].reshape(24, 784, 1024)
     _, X_ref = oalpha.weighted_average(oalpha.matrix_alpha_average(Z), Z)
     print("config 1: X max abs err %.2e (|X| max %.2f)" % (np.abs(X - X_ref).max(), np.abs(X_ref).max()))

@@ -242,21 +242,6 @@ def test_backbone_registry(monkeypatch, tmp_path):
         bb.load("dino_vitbase8")
 
 
-def test_wrn50_shaped_standin_taps():
-    """Config 1's stand-in backbone: layer2 / layer3 shapes of wide_resnet50_2, resolved by the hook mechanism,
-    forward aborted after layer3 (common.py:211-292 of the reference)."""
-    import torch
-    import patchcore.common as common
-    from patchcore import standin_cnn
-    m = standin_cnn.wrn50_shaped(3)
-    agg = common.NetworkFeatureAggregator(m, ["layer2", "layer3"], torch.device("cpu"))
-    out = agg(torch.zeros(2, 3, 224, 224))
-    assert tuple(out["layer2"].shape) == (2, 512, 28, 28) and tuple(out["layer3"].shape) == (2, 1024, 14, 14)
-    assert agg.feature_dimensions((3, 224, 224)) == [512, 1024]
-    m2 = standin_cnn.wrn50_shaped(3)
-    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
-
-
 def test_shims_construct_and_refuse_detection_calls():
     import patchcore.common as common
     import patchcore.sampler
