@@ -84,8 +84,6 @@ class VisionTransformer(nn.Module):
     def __init__(self, img_size=(224,), patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4.0, qkv_bias=False, norm_layer=nn.LayerNorm, **kwargs):
         super().__init__()
-        if num_classes != 0:
-            raise ValueError("classification head is outside the anomaly-clustering path")
         self.num_features = self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.patch_embed = PatchEmbed(img_size[0], patch_size, in_chans, embed_dim)
@@ -94,7 +92,9 @@ class VisionTransformer(nn.Module):
         self.blocks = nn.ModuleList(
             [Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
         self.norm = norm_layer(embed_dim)
-        self.head = nn.Identity()
+        # timm's ViTs (backbones.py:35-37 of the reference) carry a classification head; the clustering path stops at a
+        # tapped block, so the head only holds its checkpoint tensors (strict loading) and is never run
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         self._packed = None
         self.reset_parameters()
 
@@ -132,6 +132,8 @@ class VisionTransformer(nn.Module):
         x = self.prepare_tokens(x)
         for blk in self.blocks:
             x = blk(x)
+        if not isinstance(self.head, nn.Identity):
+            raise NotImplementedError("the classification head is outside the anomaly-clustering path (tap a block)")
         return acnative.layernorm_rows(x[:, 0].contiguous(), self.norm)
 
     def get_intermediate_layers(self, x, n=1):

@@ -240,6 +240,23 @@ def test_backbone_registry(monkeypatch, tmp_path):
     monkeypatch.setenv("AC_DINO_WEIGHTS", str(tmp_path))
     with pytest.raises(FileNotFoundError):
         bb.load("dino_vitbase8")
+    # timm's ViT-B/8 (reference backbones.py:36): same transformer + a head that is never run; its state_dict (DINO's
+    # key names + norm / head) loads strictly from $AC_TIMM_WEIGHTS/<timm model name>.pth
+    import torch
+    import patchcore.vision_transformer as vits
+    monkeypatch.delenv("AC_DINO_WEIGHTS", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    torch.manual_seed(3)
+    src = vits._vit(768, 12, 8, depth=12, num_classes=1000)
+    keys = list(src.state_dict())
+    assert keys[:4] == ["cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"]
+    assert keys[-4:] == ["norm.weight", "norm.bias", "head.weight", "head.bias"] and len(keys) == 152
+    torch.save(src.state_dict(), tmp_path / "vit_base_patch8_224.pth")
+    monkeypatch.setenv("AC_TIMM_WEIGHTS", str(tmp_path))
+    m = bb.load("vit_base")
+    assert m.weights_source.endswith("vit_base_patch8_224.pth") and tuple(m.pos_embed.shape) == (1, 785, 768)
+    assert torch.equal(m.blocks[11].mlp.fc2.weight, src.blocks[11].mlp.fc2.weight)
+    assert set(bb._TIMM_VIT) == {"vit_small", "vit_base", "vit_large", "vit_deit_base"}
 
 
 def test_shims_construct_and_refuse_detection_calls():

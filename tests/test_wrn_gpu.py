@@ -38,7 +38,7 @@ def _close(got, ref, what):
     scale = float(ref.abs().max())
     err = float((got - ref).abs().max())
     print("%s: max |err| %.2e at |x| <= %.2f (relative to the largest value %.1e)" % (what, err, scale, err / scale))
-    assert err <= 2e-5 * scale + 1e-6, what
+    assert err <= 1e-5 * scale + 1e-6, what
 
 
 def test_layer_taps_match_the_cpu_restatement(dev, wrn):
@@ -48,7 +48,7 @@ def test_layer_taps_match_the_cpu_restatement(dev, wrn):
     g = torch.Generator().manual_seed(11)
     images = torch.randn((3, 3, 224, 224), generator=g)
     agg = common.NetworkFeatureAggregator(model, ["layer2", "layer3"], dev)
-    out = agg(images.to(dev))
+    out = dict(agg(images.to(dev)))          # the aggregator hands out its own dict (as upstream): keep this call's taps
     ref = owrn.forward_taps(sd, images)
     assert tuple(out["layer2"].shape) == (3, 512, 28, 28) and tuple(out["layer3"].shape) == (3, 1024, 14, 14)
     assert agg.feature_dimensions((3, 224, 224)) == [512, 1024]
