@@ -42,7 +42,7 @@ __device__ inline void argmin_take(double& d, int& i, double d2, int i2) {
 // ------------------------------------------------------------------ nearest-neighbour chain (one workgroup)
 __global__ __launch_bounds__(1024) void ward_nn_chain_kernel(double* __restrict__ D, int n, int* __restrict__ size,
                                                              int* __restrict__ chain, double* __restrict__ Zraw,
-                                                             const int* __restrict__ bad) {
+                                                             int* __restrict__ bad) {
   if (*bad) return;                                 // block-uniform
   __shared__ double red_d[16];
   __shared__ int red_i[16];
@@ -94,12 +94,17 @@ __global__ __launch_bounds__(1024) void ward_nn_chain_kernel(double* __restrict_
         double cur = sh_cur;
         if (d < cur) { cur = d; y = i; }            // strict: ties keep the previous chain element
         const int len = sh_len;
-        if (len > 1 && y == sh_prev) { sh_done = 1; }
+        // y < 0: the chain has one element and no live distance of its row compares below +inf - they are NaN (the
+        // Lance-Williams square root of a tiny negative number, e.g. exactly collinear points).  Without a neighbour
+        // there is nothing to merge: flag it and leave, block-uniformly (chain[len] = -1 would index D out of bounds).
+        if (y < 0) { sh_done = 2; }
+        else if (len > 1 && y == sh_prev) { sh_done = 1; }
         else { chain[len] = y; sh_len = len + 1; sh_done = 0; }
         sh_y = y;
         sh_cur = cur;
       }
       __syncthreads();
+      if (sh_done == 2) { if (tid == 0) *bad = 2; return; }
       if (sh_done) break;
     }
     // merge x = chain top and y = its predecessor; fastcluster convention x < y
@@ -220,42 +225,38 @@ __global__ void contingency_kernel(const int* __restrict__ a, const int* __restr
 
 // sklearn.metrics.normalized_mutual_info_score (average_method="arithmetic") and adjusted_rand_score from the
 // contingency matrix (sklearn/metrics/cluster/_supervised.py: mutual_info_score, entropy, pair_confusion_matrix).
+constexpr int SCORES_MAX_K = 2048;
 __global__ void scores_kernel(const unsigned long long* __restrict__ C, int ka, int kb, double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // One thread (k is a handful on the path; the sums keep sklearn's left-to-right order): the row sums n_c and the
+  // column sums n_k are formed ONCE - O(ka kb) for everything below, whatever k.
+  __shared__ double rsum[SCORES_MAX_K], csum[SCORES_MAX_K];
   double N = 0.0, sum_sq = 0.0;
   int rows = 0, cols = 0;
   for (int u = 0; u < ka; ++u) {
     double r = 0.0;
     for (int v = 0; v < kb; ++v) { const double c = (double)C[(size_t)u * kb + v]; r += c; sum_sq += c * c; }
+    rsum[u] = r;
     N += r;
     rows += r > 0.0;
   }
   for (int v = 0; v < kb; ++v) {
     double c = 0.0;
     for (int u = 0; u < ka; ++u) c += (double)C[(size_t)u * kb + v];
+    csum[v] = c;
     cols += c > 0.0;
   }
   const double eps = 2.220446049250313e-16;
   // entropies and mutual information, natural logarithm
   double hu = 0.0, hv = 0.0, mi = 0.0, dot_k = 0.0, dot_c = 0.0;
   const double logN = log(N);
+  for (int u = 0; u < ka; ++u) { const double r = rsum[u]; if (r > 0.0) hu -= (r / N) * (log(r) - logN); }
+  for (int v = 0; v < kb; ++v) { const double c = csum[v]; if (c > 0.0) hv -= (c / N) * (log(c) - logN); }
   for (int u = 0; u < ka; ++u) {
-    double r = 0.0;
-    for (int v = 0; v < kb; ++v) r += (double)C[(size_t)u * kb + v];
-    if (r > 0.0) hu -= (r / N) * (log(r) - logN);
-  }
-  for (int v = 0; v < kb; ++v) {
-    double c = 0.0;
-    for (int u = 0; u < ka; ++u) c += (double)C[(size_t)u * kb + v];
-    if (c > 0.0) hv -= (c / N) * (log(c) - logN);
-  }
-  for (int u = 0; u < ka; ++u) {
-    double r = 0.0;
-    for (int v = 0; v < kb; ++v) r += (double)C[(size_t)u * kb + v];
+    const double r = rsum[u];
     for (int v = 0; v < kb; ++v) {
       const double nij = (double)C[(size_t)u * kb + v];
-      double c = 0.0;
-      for (int w = 0; w < ka; ++w) c += (double)C[(size_t)w * kb + v];
+      const double c = csum[v];
       dot_k += nij * c;                     // contingency.dot(n_k).sum()
       dot_c += nij * r;                     // contingency.T.dot(n_c).sum()
       if (nij > 0.0) {
@@ -287,7 +288,8 @@ extern "C" int ac_cluster_scores(const int32_t* labels_true, const int32_t* labe
                                  uint64_t* contingency, double* scores, int32_t* bad_label_flag, void* stream_) {
   hipStream_t stream = as_stream(stream_);
   AC_REQUIRE(labels_true && labels_pred && contingency && scores && bad_label_flag, "ac_cluster_scores: null pointer");
-  AC_REQUIRE(n > 0 && k_true > 0 && k_pred > 0 && k_true <= 4096 && k_pred <= 4096, "ac_cluster_scores: bad shape");
+  AC_REQUIRE(n > 0 && k_true > 0 && k_pred > 0 && k_true <= SCORES_MAX_K && k_pred <= SCORES_MAX_K,
+             "ac_cluster_scores: bad shape (1 <= k <= %d)", SCORES_MAX_K);
   if (hipMemsetAsync(contingency, 0, (size_t)k_true * k_pred * 8, stream) != hipSuccess ||
       hipMemsetAsync(bad_label_flag, 0, 4, stream) != hipSuccess)
     return ac_fail(AC_ELAUNCH, "ac_cluster_scores: hipMemsetAsync failed");

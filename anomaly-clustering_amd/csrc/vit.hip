@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
   const int q0 = blockIdx.x * ATT_Q + wave * 32;
+  const bool active = q0 < T;                          // wave-uniform
   const int C = H * HD;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -519,6 +520,10 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile kt has landed
     __syncthreads();                                   // ... everybody's has; tile kt-1 is fully consumed
     if (kt + 1 < ntiles) dma_tile(kt + 1);             // flies under this tile's MFMAs
+    // A wave whose 32 queries all lie beyond the sequence (T = 785: the last block of 128 queries holds 17) only helps
+    // with the DMA and the barriers: its SIMD slots go to the other workgroups of the CU (3 of the 28 wave slots per
+    // head did redundant work on clamped rows: -10 % attention time at T = 785).
+    if (!active) continue;
 
     // V^T fragments: two transposed 4-key blocks per (feature half, key group, plane), issued now so that
     // their latency hides under the S^T MFMAs and the softmax

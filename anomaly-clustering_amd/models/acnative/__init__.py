@@ -721,8 +721,12 @@ def ward_linkage(condensed, n):
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=condensed.device)      # ~8 n^2 bytes: not kept around
     bad = torch.empty(1, dtype=torch.int32, device=condensed.device)
     _check(lib().ac_ward_linkage(p, n, Z.data_ptr(), bad.data_ptr(), ws.data_ptr(), nbytes, _stream()))
-    if int(bad.item()):
+    flag = int(bad.item())
+    if flag == 1:
         raise ValueError("The condensed distance matrix must contain only finite values.")     # scipy's message
+    if flag:
+        raise ValueError("Ward linkage: the Lance-Williams update produced NaN distances (a cluster was left without a "
+                         "comparable neighbour); the input is numerically degenerate, e.g. exactly collinear points")
     return Z
 
 

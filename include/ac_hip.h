@@ -287,16 +287,17 @@ int ac_pdist(const float* X, int64_t N, int D, double* out, void* stream);
  * AgglomerativeClustering -> ward_tree.  Z: float64 [n-1, 4] = (cluster a, cluster b, distance, size), rows
  * sorted by distance (stable), ids relabelled as scipy does - bit-identical to scipy's Z on the same input.
  * `condensed` is not modified.  n <= 46000; workspace ~ 8 n^2 bytes.  bad_input_flag: int32 [1] (device), set to 1
- * when a distance is NaN or infinite (scipy raises ValueError there); Z is then left unwritten - the caller checks
- * the flag after synchronising. */
+ * when a distance is NaN or infinite (scipy raises ValueError there), to 2 when the Lance-Williams update itself
+ * produced NaN and a cluster was left without a comparable neighbour (numerically degenerate input); Z is then left
+ * unwritten - the caller checks the flag after synchronising. */
 size_t ac_ward_workspace_bytes(int64_t n);
 int ac_ward_linkage(const double* condensed, int64_t n, double* Z, int32_t* bad_input_flag, void* ws, size_t ws_bytes,
                     void* stream);
 
 /* Contingency matrix of two integer labelings (values in [0, k_true) / [0, k_pred)) and, from it, sklearn's
  * normalized_mutual_info_score and adjusted_rand_score (examples/test.py:218-219).
- * contingency: uint64 [k_true, k_pred] (out); scores: float64 [2] = {NMI, ARI}; bad_label_flag: int32 [1], set to 1
- * when a label lies outside its range (the caller checks it after synchronising). */
+ * contingency: uint64 [k_true, k_pred] (out), k <= 2048; scores: float64 [2] = {NMI, ARI}; bad_label_flag: int32 [1],
+ * set to 1 when a label lies outside its range (the caller checks it after synchronising). */
 int ac_cluster_scores(const int32_t* labels_true, const int32_t* labels_pred, int64_t n, int k_true, int k_pred,
                       uint64_t* contingency, double* scores, int32_t* bad_label_flag, void* stream);
 

@@ -1,4 +1,4 @@
-# Run on the GPU box:  gpurun --timeout 1200 -- bash profiles/collect_r03.sh [config] [tag]
+# Run on the GPU box:  gpurun --timeout 1200 -- bash profiles/collect_r03.sh [config] [tag] [steps]
 # bench + rocprofv3 kernel stats + PMC passes (HBM bytes, clock, MFMA pipe) + the stall-attribution SQ passes of
 # VERDICT r02 item 3.  Every rocprofv3 command has the program itself after `--`; --pmc passes carry --kernel-trace only.
 # Then here:  python profiles/summarize.py gpurun_out/prof_r03_<tag>/flat r03_<tag> "<workload key>"
@@ -6,12 +6,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 CFG=${1:-2}
 TAG=${2:-bench}
+STEPS=${3:-5}
 O=$R/gpurun_out/prof_r03_$TAG
 rm -rf $O; mkdir -p $O/flat
 B="python3 $R/bench.py --config $CFG"
-timeout 900 $B --steps 5 --warmup 1 > $O/bench_plain.json 2>$O/bench_plain.err || exit 1
+timeout 900 $B --steps $STEPS --warmup 1 > $O/bench_plain.json 2>$O/bench_plain.err || exit 1
 echo "plain bench done"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2>$O/stats.err || exit 1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps $STEPS --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2>$O/stats.err || exit 1
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/flat/ \;
 rm -rf $O/stats
 echo "kernel stats done"
@@ -38,4 +39,4 @@ if [ "$CFG" = "2" ]; then
   pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VALU_MFMA_COEXEC_CYCLES || exit 1
   pass l2 TCC_HIT_sum TCC_MISS_sum || exit 1
 fi
-tail -c 400 $O/bench_plain.json; echo; ls $O/flat; cat $O/missing.txt 2>/dev/null
+tail -c 400 $O/bench_plain.json; echo; ls $O/flat; cat $O/missing.txt 2>/dev/null; exit 0

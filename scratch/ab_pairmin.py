@@ -67,7 +67,9 @@ def main():
         print("%-12s median %.3f ms  min %.3f  max %.3f  (%.0f TFLOP/s algorithmic at the median)  bit-equal to %s: %s"
               % (name, statistics.median(t), min(t), max(t), flop / statistics.median(t) / 1e9, libs[0][0], same[name]))
     # vendor reference on the same box: fp16 GEMM through torch (hipBLASLt / rocBLAS), random operands
-    for (m, n, k) in [(8192, 8192, 8192), (32768, 32768, 4096)]:
+    # ... and at the shapes of the ViT linear layers at 83 images (qkv, proj, fc1, fc2)
+    for (m, n, k) in [(8192, 8192, 8192), (32768, 32768, 4096), (65155, 2304, 768), (65155, 768, 768), (65155, 3072, 768),
+                      (65155, 768, 3072)]:
         A = torch.randn((m, k), device=dev, dtype=torch.float16)
         B = torch.randn((n, k), device=dev, dtype=torch.float16)
         C = A @ B.T
@@ -83,6 +85,24 @@ def main():
         print("torch fp16 matmul %dx%dx%d (vendor library, random operands): median %.3f ms = %.0f TFLOP/s"
               % (m, n, k, statistics.median(ts), 2.0 * m * n * k / statistics.median(ts) / 1e9))
         del A, B, C
+    # vendor attention (torch SDPA: the library's fused fp16 kernel) at the ViT-B/8 shape of 83 images
+    try:
+        import torch.nn.functional as F
+        q, k, v = (torch.randn((83, 12, 785, 64), device=dev, dtype=torch.float16) for _ in range(3))
+        o = F.scaled_dot_product_attention(q, k, v)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = F.scaled_dot_product_attention(q, k, v)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        fl = 83 * 12 * 4.0 * 785 * 785 * 64
+        print("torch SDPA fp16 [83,12,785,64] (single pass): median %.3f ms = %.0f TFLOP/s" % (statistics.median(ts), fl / statistics.median(ts) / 1e9))
+    except Exception as e:          # noqa: BLE001
+        print("torch SDPA not available:", e)
 
 
 if __name__ == "__main__":

@@ -40,3 +40,30 @@ def test_bench_config_5b_small():
 def test_bench_config_5a_small():
     d = _bench("--config", "5a", "--n", "24", "--no-cpu-baseline", "--steps", "1")
     assert REQUIRED <= set(d) and d["roofline"]["kernel"].startswith("ViT forward") and d["roofline"]["frac"] < 1 / 3
+
+
+def _check_all15(d, mode):
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["unit"] == "images/sec" and d["scaling"] == "strong"
+    assert d["config"]["images_per_step"] == 1725 and d["config"]["categories"] == 15
+    per = d["per_category"]
+    assert [c["n"] for c in per] == [83, 150, 132, 117, 78, 110, 124, 115, 167, 160, 117, 42, 100, 79, 151]
+    assert all(c["ms"] > 0 and c["images_per_sec"] > 0 for c in per)
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and roof["launches_per_step"] == 15
+    # every ordered image pair of every category (bank: N test x M = N bank images) resolved exactly once per step
+    pairs = sum(n * (n - 1.0) if mode == "unsupervised" else n * 1.0 * n for n in (c["n"] for c in per))
+    total = roof["algorithmic_flop_per_launch"] * roof["launches"] / d["steps"]
+    assert abs(total - pairs * 2.0 * 784 * 784 * 4096) / total < 1e-9
+    assert 0 < roof["frac"] < (2 / 3 if mode == "unsupervised" else 1.0)
+    # the committed PMC summary of THIS workload (profiles/r03_config*_pmc.json) supplies the HBM-side bytes
+    assert roof["traffic"] is not None and roof["traffic"] > 0 and roof["traffic_source"].startswith("profiles/")
+    assert set(d["stage_ms"]) >= {"embed", "pair_min_dist", "pdist"} and d["h2d_inclusive"]["value"] > 0
+
+
+def test_bench_config_3_all_fifteen_categories():
+    """BASELINE config 3 end to end through bench.py on one GPU (the 8-GPU run is the driver's): ~5 s."""
+    _check_all15(_bench("--config", "3", "--gpus", "1", "--no-cpu-baseline", "--steps", "1"), "unsupervised")
+
+
+def test_bench_config_4_supervised():
+    _check_all15(_bench("--config", "4", "--gpus", "1", "--no-cpu-baseline", "--steps", "1"), "supervised")
