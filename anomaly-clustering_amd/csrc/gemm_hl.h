@@ -83,6 +83,11 @@ constexpr int EPI_PITCH = 68;   // floats per staged row: 16-byte aligned, confl
 // rows x 64 (hl32) or 128 (fp32) contiguous bytes.
 template <class E, class = void> struct HasSwap : std::false_type {};
 template <class E> struct HasSwap<E, std::void_t<decltype(E::kSwap)>> : std::bool_constant<E::kSwap> {};
+// An epilogue may also take the wave's whole accumulator at once (`static constexpr bool kWholeTile = true` and
+// `swapped_tile(acc[4][NT], m_wave, n_wave, lane)`; gemm_hl5.h calls it instead of NT/4 swapped() calls) - for
+// epilogues that read memory and want their loads in flight across the 64-column fragments.
+template <class E, class = void> struct HasWholeTile : std::false_type {};
+template <class E> struct HasWholeTile<E, std::void_t<decltype(E::kWholeTile)>> : std::bool_constant<E::kWholeTile> {};
 struct SwapFrag {
   __device__ static int row(int mi, int lane) { return mi * 16 + (lane & 15); }
   __device__ static int col8(int p, int lane) { return 32 * p + 8 * (lane >> 4); }

@@ -279,6 +279,10 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
 
   // epilogue: the wave's 64 x (NT*16) accumulator as NT/4 64x64 fragments of the common epilogue interface
   const int m_wave = m0 + wm * 64;
+  if constexpr (SWAP && gemm::HasWholeTile<Epi>::value) {
+    epi.template swapped_tile<NT>(acc, m_wave, n0 + wn * (NT * 16), lane);
+    return;
+  }
 #pragma unroll
   for (int no = 0; no < NT / 4; ++no) {
     Frag f;

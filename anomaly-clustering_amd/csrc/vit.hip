@@ -306,6 +306,66 @@ struct EpiResidual {
       }
     }
   }
+  // The wave's WHOLE accumulator (64 rows x NT*16 columns; gemm_hl5.h) in one call: the residual comes in groups of
+  // 32 columns (8 x 16-byte loads per lane), and group q + 2 is requested before group q is summed and stored, so two
+  // groups are always in flight.  Through swapped() the same tile takes four dependent round trips (loads -> wait ->
+  // stores, four times: `out` may alias `res`, so the compiler may not move a load above an earlier store), each a
+  // full memory latency while all 256 CUs burst their epilogues at once - ~13 us per tile more than an epilogue
+  // without loads (round 3).  Each element is still loaded before it is stored, by the same
+  // lane, so the in-place update x += f(x) stays correct.  Loads use clamped rows / columns; only stores are masked.
+#ifndef AC_RES_NO_PIPELINE     // (same-box A/B knob of scratch/ab_vit.py; never defined in the product build)
+  static constexpr bool kWholeTile = true;
+#endif
+  template <int NT>
+  __device__ void swapped_tile(const f32x4 (&acc)[4][NT], int m_wave, int n_wave, int lane) const {
+    using S = gemm::SwapFrag;
+    constexpr int Q = NT / 2;
+    if (m_wave >= M) return;                          // wave-uniform: nothing of this wave's 64 rows exists
+    f32x4 r[Q][4][2], bv[Q][2];     // the bias vectors travel WITH their group: a load issued right before its use
+    const float* rowp[4];           // would drain the whole queue (vmcnt counts in issue order)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) rowp[mi] = res + (size_t)min(m_wave + S::row(mi, lane), M - 1) * N;
+    const int c0 = n_wave + 8 * (lane >> 4);
+    auto load = [&](int q) {
+      const int col = min(c0 + 32 * q, N - 8);
+      bv[q][0] = *reinterpret_cast<const f32x4*>(bias + col);
+      bv[q][1] = *reinterpret_cast<const f32x4*>(bias + col + 4);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        r[q][mi][0] = *reinterpret_cast<const f32x4*>(rowp[mi] + col);
+        r[q][mi][1] = *reinterpret_cast<const f32x4*>(rowp[mi] + col + 4);
+      }
+    };
+    // Stores go through a buffer resource that spans exactly this wave's valid rows ((M - m_wave) rows, at most 64):
+    // a row beyond M is out of range and the hardware drops the store - no exec-mask branch, so the compiler counts
+    // its vmcnt waits exactly instead of draining to 0 at every branch.  A column beyond N gets an out-of-range
+    // offset the same way.
+    const int rows_here = min(64, M - m_wave);        // >= 1 (checked above): the resource never spans a missing row
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)m_wave * N, 0, rows_here * N * 4, 0x00020000);
+    auto finish = [&](int q) {
+      const int col = c0 + 32 * q;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        f32x4 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o0[j] = r[q][mi][0][j] + (acc[mi][2 * q][j] + bv[q][0][j]);
+          o1[j] = r[q][mi][1][j] + (acc[mi][2 * q + 1][j] + bv[q][1][j]);
+        }
+        const unsigned off = col < N ? (unsigned)(S::row(mi, lane) * N + col) * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), orsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), orsrc, off + 16u, 0, 0);
+      }
+    };
+    load(0);
+    if constexpr (Q > 1) load(1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q + 2 < Q) load(q + 2);
+      finish(q);
+    }
+  }
 };
 
 // exact-erf GELU (nn.GELU default): 0.5 v (1 + erf(v / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26
@@ -523,7 +583,9 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     // A wave whose 32 queries all lie beyond the sequence (T = 785: the last block of 128 queries holds 17) only helps
     // with the DMA and the barriers: its SIMD slots go to the other workgroups of the CU (3 of the 28 wave slots per
     // head did redundant work on clamped rows: -10 % attention time at T = 785).
+#ifndef AC_ATT_NO_SKIP        // (same-box A/B knob of scratch/ab_vit.py; never defined in the product build)
     if (!active) continue;
+#endif
 
     // V^T fragments: two transposed 4-key blocks per (feature half, key group, plane), issued now so that
     // their latency hides under the S^T MFMAs and the softmax
