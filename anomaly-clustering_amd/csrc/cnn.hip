@@ -83,9 +83,11 @@ extern "C" int ac_conv_gemm_bn(const void* A_hl32, const void* W_hl32, int64_t M
              "ac_conv_gemm_bn: bad shape M=%lld N=%d K=%d (N %% 8 == 0, K %% 32 == 0)", (long long)M, N, K);
   EpiConvBN epi{alpha, beta, res, out, (int)M, N, relu};
   const int policy = ac_gemm_policy();
-  const long long tiles5 = ((M + 255) / 256) * ((N + 255) / 256);
-  // 256x256 tiles unless they would leave half the CUs idle or waste half of every tile (N <= 128)
-  const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && 2 * tiles5 > ac_device_cus() && N > 128);
+  // the tile shape that finishes first in whole rounds of the chip (the rule of vit.hip's run_gemm)
+  const long long cus = ac_device_cus();
+  const long long tiles5 = ((M + 255) / 256) * ((N + 255) / 256), tiles2 = ((M + 255) / 256) * ((N + 127) / 128);
+  const double cost5 = (double)((tiles5 + cus - 1) / cus), cost2 = 0.54 * (double)((tiles2 + cus - 1) / cus);
+  const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && cost5 <= cost2);
   if (big) return gemm5::launch<EpiConvBN>(A_hl32, W_hl32, (int)M, N, K, epi, as_stream(stream));
   return gemm2::launch<EpiConvBN, false>(A_hl32, W_hl32, (int)M, N, K, epi, as_stream(stream), 8, 0, 1);
 }

@@ -18,8 +18,7 @@
 constexpr int HD = 64;          // head dim (all DINO ViTs)
 
 // Linear layers: the 256x256 kernel (gemm_hl5.h), or - for small problems, e.g. a rank's shard of a category
-// on 8 GPUs - the 256x128 kernel (gemm_hl2.h): when the 256x256 tiles would fill at most half the CUs, half-size
-// tiles do the same work in one round (measured at 11 images: ViT block 0.71 -> 0.61 ms, equal from 21 images up).
+// on 8 GPUs - the 256x128 kernel (gemm_hl2.h), whichever needs less time in whole rounds of the chip (below).
 // The two kernels give bit-identical results (tests/test_gemm_generations_gpu.py); ac_set_gemm_policy() pins
 // one of them for that test and for same-box A/B timing.
 template <class Epi>
@@ -34,8 +33,20 @@ static int run_gemm(const void* A, const void* B, int M, int N, int K, const Epi
   // round 2 - bit-identical, 2.5 % SLOWER than the 8-wave 256x256 kernel on a ViT block at 83 images
   if (policy == 107) return gemm5::launch<Epi, 4, false, 3>(A, B, M, N, K, epi, stream);
 #endif
+  // AUTO: the tile shape that finishes first on this chip.  One workgroup per CU at a time, so a launch takes
+  // ceil(tiles / CUs) rounds; a 256x128 tile costs 0.54 of a 256x256 tile (half the work at ~8 % less efficiency:
+  // DESIGN.md section 4).  At 83 images both rules pick 256x256 everywhere; at a rank's 11 or 21 images of an 8- or
+  // 4-GPU run the half-size tiles fill the last round (qkv at 11 images: 306 big tiles = 2 rounds vs 612 small = 3
+  // rounds x 0.54 = 1.6).
+  const long long cus = ac_device_cus();
   const long long tiles5 = (long long)((M + 255) / 256) * ((N + 255) / 256);
-  const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && 2 * tiles5 > ac_device_cus());
+  const long long tiles2 = (long long)((M + 255) / 256) * ((N + 127) / 128);
+  const double cost5 = (double)((tiles5 + cus - 1) / cus), cost2 = 0.54 * (double)((tiles2 + cus - 1) / cus);
+#ifdef AC_OLD_TILE_RULE          // (same-box A/B knob: round 2's rule - half-size tiles only when they fit one round)
+  const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && 2 * tiles5 > cus);
+#else
+  const bool big = policy == AC_GEMM_256x256 || (policy != AC_GEMM_256x128 && cost5 <= cost2);
+#endif
   if (big) return gemm5::launch<Epi>(A, B, M, N, K, epi, stream);
   return gemm2::launch<Epi, false>(A, B, M, N, K, epi, stream, 8, 0, 1);
 }
