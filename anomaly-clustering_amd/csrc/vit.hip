@@ -585,7 +585,12 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
   dma_tile(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // One key tile.  MASKED (a compile-time tag): only the last tile can hold keys >= T.  As a run-time condition inside
+  // one loop body hipcc turned the block-uniform branch into selects - 16 v_cmp + 16 v_cndmask + the key indices,
+  // ~58 of ~330 instructions of EVERY tile, in a loop whose VALU issue is as busy as its MFMA pipe - so the last tile
+  // is peeled into its own instantiation.
+  auto key_tile = [&](const int kt, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int key0 = kt * ATT_KT;
     const uint8_t* Ks = lds + (kt & 1) * ATT_TILE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile kt has landed
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     // with the DMA and the barriers: its SIMD slots go to the other workgroups of the CU (3 of the 28 wave slots per
     // head did redundant work on clamped rows: -10 % attention time at T = 785).
 #ifndef AC_ATT_NO_SKIP        // (same-box A/B knob of scratch/ab_vit.py; never defined in the product build)
-    if (!active) continue;
+    if (!active) return;
 #endif
 
     // V^T fragments: two transposed 4-key blocks per (feature half, key group, plane), issued now so that
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     // tile has padded keys (block-uniform branch); the O / l rescale is skipped (wave-uniform
     // branch) whenever no lane's running maximum moved.  Accumulator element i of lane half h is
     // key key0 + 16(i>>3) + 8h + (i&7) (see pi above).
-    if (key0 + ATT_KT > T) {
+    if constexpr (MASKED) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         int key = key0 + 16 * (i >> 3) + 8 * h + (i & 7);
@@ -686,7 +691,10 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
           o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[mt], 0, 0, 0);
         }
     }
-  }
+  };
+  for (int kt = 0; kt + 1 < ntiles; ++kt) key_tile(kt, std::false_type{});
+  if (ntiles * ATT_KT > T) key_tile(ntiles - 1, std::true_type{});
+  else key_tile(ntiles - 1, std::false_type{});
   // normalise, transpose through LDS ([32 q][65] floats per wave), write hl32 lines
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
