@@ -51,94 +51,6 @@ extern "C" int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_l
   return ac_check_launch("pack_hl32");
 }
 
-// fp32 [rows, K] -> distance operand (common.h "hl32d"): data groups as in hl32, a norm group after every 32 of them.
-// One wave per row; a trip covers 512 k values (16 groups), two trips make a chunk.
-// scale_exp (device, nullable = 0): every value is multiplied by 2^-e first (exact) - the category-wide power of two that
-// keeps every chunk's half squared norm inside fp16's range (ac_dist_scale); distances come out scaled by 2^-e and the
-// finalize kernels scale them back.  only_if_scaled: the second, conditional pass - return at once when e == 0.
-__global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict__ src, int64_t rows, int K, int64_t ld,
-                                                        uint8_t* __restrict__ dst, float* __restrict__ sqnorm,
-                                                        const int* __restrict__ scale_exp, int only_if_scaled) {
-  const int e = scale_exp ? scale_exp[0] : 0;
-  if (only_if_scaled && e == 0) return;                               // grid-uniform
-  const float sc = ldexpf(1.f, -e);
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* s = src + row * ld;
-  uint8_t* d = dst + (size_t)row * dist_k(K) * 4;
-  const int groups = K / 32;
-  double acc = 0.0, chunk = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 512) {
-    const int k = k0 + lane * 8;
-    if (k < K) {
-      float v[8];
-      *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(s + k);
-      *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(s + k + 4);
-      double part = 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { v[j] *= sc; part += (double)v[j] * (double)v[j]; }
-      chunk += part;
-      store_hl32_8(d, k + 32 * ((k >> 5) / DIST_CHUNK_GROUPS), v);     // shifted by the norm groups in front of it
-    }
-    const int g_end = min(groups, (k0 + 512) / 32);                    // data groups written so far
-    if (g_end % DIST_CHUNK_GROUPS == 0 || g_end == groups) {           // a chunk is complete: its norm group
-      const double n = wave_sum(chunk);                                // (the butterfly leaves the sum in every lane)
-      acc += n;
-      chunk = 0.0;
-      const float x = (float)(-0.5 * n);
-      const _Float16 p1 = (_Float16)x;
-      const float r1 = x - (float)p1;
-      const _Float16 p2 = (_Float16)r1;
-      const _Float16 p3 = (_Float16)(r1 - (float)p2);
-      if (lane < 8) {
-        half8 piece = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (lane == 0) { piece[0] = (_Float16)1.f; piece[1] = (_Float16)1.f; piece[2] = (_Float16)1.f; }
-        if (lane == 4) { piece[0] = p1; piece[1] = p2; piece[2] = p3; }
-        *reinterpret_cast<half8*>(d + (size_t)(dist_group_pos(g_end - 1) + 1) * 128 + lane * 16) = piece;
-      }
-    }
-  }
-  if (sqnorm && lane == 0) sqnorm[row] = (float)acc;                   // of the SCALED row
-}
-
-extern "C" size_t ac_dist_row_bytes(int K) { return K > 0 && K % 32 == 0 ? (size_t)dist_k(K) * 4 : 0; }
-
-extern "C" int ac_pack_dist(const float* src, int64_t rows, int K, int64_t src_ld, void* dst, float* row_sqnorm,
-                            const int32_t* scale_exp, int only_if_scaled, void* stream) {
-  AC_REQUIRE(src && dst, "ac_pack_dist: null pointer");
-  AC_REQUIRE(K > 0 && K % 32 == 0, "ac_pack_dist: K=%d must be a positive multiple of 32", K);
-  AC_REQUIRE(src_ld >= K && src_ld % 4 == 0, "ac_pack_dist: src_ld=%lld must be >= K and a multiple of 4", (long long)src_ld);
-  AC_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "ac_pack_dist: pointers must be 16-byte aligned");
-  AC_REQUIRE(!only_if_scaled || scale_exp, "ac_pack_dist: the conditional pass needs scale_exp");
-  if (rows <= 0) return AC_OK;
-  int64_t blocks = (rows + 3) / 4;
-  AC_REQUIRE(blocks <= 0x7fffffff, "ac_pack_dist: too many rows");
-  hipLaunchKernelGGL(pack_dist_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, rows, K, src_ld,
-                     static_cast<uint8_t*>(dst), row_sqnorm, scale_exp, only_if_scaled);
-  return ac_check_launch("pack_dist");
-}
-
-// The category-wide scale of the distance operands: the smallest e >= 0 with  max |row|^2 * 4^-e / 2 < 60000  (a chunk's
-// half squared norm is at most the row's and must fit fp16; ordinary features: e = 0).  max_sq is rewritten in scaled units.
-__global__ void dist_scale_kernel(float* __restrict__ max_sq, int* __restrict__ scale_exp) {
-  const double m = (double)max_sq[0];
-  int e = 0;
-  if (m * 0.5 >= 60000.0 && m < 1e300) {          // (inf / NaN norms stay unscaled and propagate, as in the reference)
-    int k = 0;
-    (void)frexp(m * 0.5 / 60000.0, &k);            // m/2/60000 < 2^k
-    e = (k + 1) / 2;
-  }
-  scale_exp[0] = e;
-  max_sq[0] = (float)ldexp(m, -2 * e);
-}
-
-extern "C" int ac_dist_scale(float* max_sq, int32_t* scale_exp, void* stream) {
-  AC_REQUIRE(max_sq && scale_exp, "ac_dist_scale: null pointer");
-  hipLaunchKernelGGL(dist_scale_kernel, dim3(1), dim3(1), 0, as_stream(stream), max_sq, scale_exp);
-  return ac_check_launch("ac_dist_scale");
-}
-
 // ------------------------------------------------- pair-min-distance epilogue
 // GEMM orientation: A (rows -> accumulator registers) = KEY patches, flat over all key
 // images; B (columns -> lanes) = QUERY patches.  d2(key, q) = |key|^2 + |q|^2 - 2 key.q,
@@ -147,26 +59,33 @@ extern "C" int ac_dist_scale(float* max_sq, int32_t* scale_exp, void* stream) {
 // atomicMin per (key image, query column) into minbuf[key_image][query] (d2 >= 0, so the
 // IEEE bit pattern orders like an unsigned integer).
 struct EpiPairMin {
+  const float* key_sq;   // [M]  squared norms of the A rows
+  const float* qry_sq;   // [N]  squared norms of the B rows
   unsigned* minbuf;      // [images of A][N]: min over the A patches of one image, per B patch
   unsigned* minbuf_t;    // [images of B][M]: the other direction (symmetric: == minbuf; two-way: its own matrix)
   int M, N, P;
-  float bias2;           // 6 * (norm groups per row): the accumulator holds 3 per norm group - |key - q|^2 / 2 (common.h)
   // upper_only (diagonal blocks of a symmetric problem): elements with row > column are left out - the
   // mirror element, formed with the lower row as the A operand, stands for both.
   template <class F>
   __device__ void operator()(const F& f, int m_wave, int n_wave, int lane, bool upper_only = false) const {
     if (m_wave >= M) return;                      // wave-uniform
     const int m_end = min(m_wave + 64, M);
+    float ksq[F::NT][F::NR];
+#pragma unroll
+    for (int mi = 0; mi < F::NT; ++mi)
+#pragma unroll
+      for (int i = 0; i < F::NR; ++i) ksq[mi][i] = key_sq[min(m_wave + F::row(mi, i, lane), M - 1)];
     const int img_first = m_wave / P, img_last = (m_end - 1) / P;
 #pragma unroll
     for (int ni = 0; ni < F::NT; ++ni) {
       const int col = n_wave + F::col(ni, lane);
+      const float qs = qry_sq[min(col, N - 1)];
       float d2[F::NT][F::NR];
 #pragma unroll
       for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
-        for (int i = 0; i < F::NR; ++i) {  // acc = 3 * groups - |key - q|^2 / 2 (the norm groups of the operands)
-          const float v = fmaxf(fmaf(-2.f, f.acc[mi][ni][i], bias2), 0.f);
+        for (int i = 0; i < F::NR; ++i) {  // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
+          const float v = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
           d2[mi][i] = (upper_only && m_wave + F::row(mi, i, lane) > col) ? __builtin_inff() : v;
         }
       for (int img = img_first; img <= img_last; ++img) {   // wave-uniform trip count (<= 2 when P >= 64)
@@ -192,17 +111,23 @@ struct EpiPairMin {
   template <class F>
   __device__ void transposed(const F& f, int m_wave, int n_wave, int lane, float* tb, bool upper_only = false) const {
     if (m_wave >= M || n_wave >= N) return;       // wave-uniform
+    float ksq[F::NT][F::NR];
+#pragma unroll
+    for (int mi = 0; mi < F::NT; ++mi)
+#pragma unroll
+      for (int i = 0; i < F::NR; ++i) ksq[mi][i] = key_sq[min(m_wave + F::row(mi, i, lane), M - 1)];
     const int my_row = m_wave + lane;
 #pragma unroll
     for (int ni = 0; ni < F::NT; ++ni) {
       const int c_base = n_wave + ni * F::TW;
       if (c_base >= N) break;                      // wave-uniform
       const int cl = F::col(ni, lane) - ni * F::TW;
+      const float qs = qry_sq[min(c_base + cl, N - 1)];
 #pragma unroll
       for (int mi = 0; mi < F::NT; ++mi)
 #pragma unroll
         for (int i = 0; i < F::NR; ++i) {
-          const float v = fmaxf(fmaf(-2.f, f.acc[mi][ni][i], bias2), 0.f);
+          const float v = fmaxf((ksq[mi][i] - f.acc[mi][ni][i]) + (qs - f.acc[mi][ni][i]), 0.f);
           tb[cl * 65 + F::row(mi, i, lane)] =
               (upper_only && m_wave + F::row(mi, i, lane) > c_base + cl) ? __builtin_inff() : v;
         }
@@ -224,24 +149,25 @@ struct EpiPairMin {
 };
 template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; static constexpr bool kStaged = false; };
 
-// The all-pairs kernel.  Round 3: the operands carry NORM GROUPS (common.h), so the MFMA accumulator itself holds
-// -|a - b|^2 / 2 chunk by chunk and needs no second accumulator - which is what kept the distance off gemm_hl5.h's
-// 256x256 tile (half the operand bytes per MFMA of the 256x128 tile; round 1 measured it 9-10 % faster and 6x further
-// from the float64 truth with a single accumulation of the plain dot product).  K here is dist_k(D): the data groups plus
-// one norm group per 32 of them (+3.1 % MFMA work at D = 4096).  ac_set_gemm_policy(AC_GEMM_256x128) pins round 2's
-// 256x128 two-accumulator kernel on the same operands (same-box A/B; results differ in the last bits).
+// The all-pairs kernel is gemm_hl2.h's 256x128 ring kernel with two-level accumulation (FLUSH): the only tile
+// whose per-wave state leaves room for the second accumulator that fp32-grade distances need (DESIGN.md
+// section 2; the 256x256 stream without it is 10 % faster and 6x further from the fp64 truth).
+// L2 window of the rasterisation: 6 tile rows per group (the 32 workgroups an XCD runs at a time then share 6 row
+// panels and ~6 column panels); same-box A/B over 2..16 rows and two tile orders: profiles/r02_raster_ab.txt.
 static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream,
                            int part = 0, int nparts = 1) {
   const int group_m = 6;
-  const int v = ac_gemm_policy();
 #ifdef AC_EXPERIMENTAL
+  const int v = epi.two_way ? 0 : ac_gemm_policy();
+  if (v == 101 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
+  if (v == 103 && nparts == 1 && !epi.symmetric) return gemm3::launch(A, B, M, N, K, epi, stream, 4);
   if (v == 104) return gemm4::launch<EpiPairMin, 0>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 105) return gemm4::launch<EpiPairMin, 1>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 106) return gemm6::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 109) return gemm5::launch<EpiPairMin, 4, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+  if (v == 108) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, 4, part, nparts);   // single accumulation
 #endif
-  if (v == AC_GEMM_256x128) return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
-  return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, 4, part, nparts);
+  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
 }
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {
@@ -349,26 +275,25 @@ extern "C" int ac_pair_accumulate(const uint32_t* minbuf, int64_t nk, int64_t ld
 }
 
 __global__ void pair_finalize_kernel(const void* __restrict__ acc, int64_t ncols, int reduce, int64_t count,
-                                     const int* __restrict__ shift_p, const int* __restrict__ scale_exp, float* __restrict__ w) {
+                                     const int* __restrict__ shift_p, float* __restrict__ w) {
   int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncols) return;
-  const int e = scale_exp ? scale_exp[0] : 0;     // the operands were scaled by 2^-e: so were the distances
   if (reduce == AC_REDUCE_MEAN_OTHERS) {
-    const double sum = ldexp((double)static_cast<const long long*>(acc)[col], e - shift_p[0]);
+    const double sum = ldexp((double)static_cast<const long long*>(acc)[col], -shift_p[0]);
     w[col] = (float)(sum / (double)count);        // count == 0 -> NaN, as torch.mean of an empty tensor
   } else {
-    w[col] = ldexpf(sqrtf(__uint_as_float(static_cast<const unsigned*>(acc)[col])), e);
+    w[col] = sqrtf(__uint_as_float(static_cast<const unsigned*>(acc)[col]));
   }
 }
 
-extern "C" int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift,
-                                const int32_t* scale_exp, float* w, void* stream) {
+extern "C" int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift, float* w,
+                                void* stream) {
   AC_REQUIRE(acc && w, "ac_pair_finalize: null pointer");
   AC_REQUIRE(reduce == AC_REDUCE_MEAN_OTHERS || reduce == AC_REDUCE_MIN_ALL, "ac_pair_finalize: bad reduce=%d", reduce);
   AC_REQUIRE(reduce == AC_REDUCE_MIN_ALL || shift, "ac_pair_finalize: the mean needs the fixed-point shift");
   if (ncols <= 0) return AC_OK;
   hipLaunchKernelGGL(pair_finalize_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, as_stream(stream), acc,
-                     ncols, reduce, count, shift, scale_exp, w);
+                     ncols, reduce, count, shift, w);
   return ac_check_launch("ac_pair_finalize");
 }
 
@@ -383,8 +308,7 @@ static int64_t query_chunk(int64_t nq, int64_t nk, int P) {
 
 extern "C" size_t ac_pair_min_dist_workspace_bytes(int64_t nq, int64_t nk, int P, int D) {
   if (nq <= 0 || nk <= 0 || P <= 0 || D <= 0) return 256;
-  const size_t rb = ac_dist_row_bytes(D);
-  size_t hl_k = align_up((size_t)nk * P * rb, 256), hl_q = align_up((size_t)nq * P * rb, 256);
+  size_t hl_k = align_up((size_t)nk * P * D * 4, 256), hl_q = align_up((size_t)nq * P * D * 4, 256);
   size_t n_k = align_up((size_t)nk * P * 4, 256), n_q = align_up((size_t)nq * P * 4, 256);
   size_t mb = align_up((size_t)query_chunk(nq, nk, P) * P * nk * 4, 256);
   size_t acc = align_up((size_t)nq * P * 8, 256);
@@ -405,10 +329,9 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
                    ac_pair_min_dist_workspace_bytes(nq, nk, P, D));
   Arena ar(ws, ws_bytes);
   const bool same = (Zq == Zk && nq == nk);
-  const size_t rb = ac_dist_row_bytes(D);
-  uint8_t* hk = ar.take<uint8_t>((size_t)nk * P * rb);
+  uint8_t* hk = ar.take<uint8_t>((size_t)nk * P * D * 4);
   float* sk = ar.take<float>((size_t)nk * P);
-  uint8_t* hq = same ? hk : ar.take<uint8_t>((size_t)nq * P * rb);
+  uint8_t* hq = same ? hk : ar.take<uint8_t>((size_t)nq * P * D * 4);
   float* sq = same ? sk : ar.take<float>((size_t)nq * P);
   const int64_t chunk = query_chunk(nq, nk, P);
   unsigned* minbuf = ar.take<unsigned>((size_t)chunk * P * nk);
@@ -417,23 +340,20 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
   int32_t* shift = reinterpret_cast<int32_t*>(max_sq + 32);
   if (!ar.ok()) return ac_fail(AC_EWORKSPACE, "ac_pair_min_dist: workspace carve failed");
 
-  int32_t* scale_exp = shift + 1;
-  // pack (unscaled) -> largest squared norm -> category scale e -> (only if e > 0) pack again scaled by 2^-e
-  int rc = ac_pack_dist(Zk, nk * P, D, D, hk, sk, nullptr, 0, stream_);
+  int rc = ac_pack_hl32(Zk, nk * P, D, D, hk, sk, stream_);
   if (rc) return rc;
-  if (!same && (rc = ac_pack_dist(Zq, nq * P, D, D, hq, sq, nullptr, 0, stream_))) return rc;
-  if (hipMemsetAsync(max_sq, 0, 256, stream) != hipSuccess) return ac_fail(AC_ELAUNCH, "ac_pair_min_dist: hipMemsetAsync failed");
-  if ((rc = ac_max_f32(sk, nk * P, max_sq, stream_))) return rc;
-  if (!same && (rc = ac_max_f32(sq, nq * P, max_sq, stream_))) return rc;
-  if ((rc = ac_dist_scale(max_sq, scale_exp, stream_))) return rc;
-  if ((rc = ac_pack_dist(Zk, nk * P, D, D, hk, sk, scale_exp, 1, stream_))) return rc;
-  if (!same && (rc = ac_pack_dist(Zq, nq * P, D, D, hq, sq, scale_exp, 1, stream_))) return rc;
+  if (!same) {
+    rc = ac_pack_hl32(Zq, nq * P, D, D, hq, sq, stream_);
+    if (rc) return rc;
+  }
   const bool mean = reduce == AC_REDUCE_MEAN_OTHERS;
   const size_t ncols_all = (size_t)nq * P;
   if (mean) {
-    if (hipMemsetAsync(acc, 0, ncols_all * 8, stream) != hipSuccess)
+    if (hipMemsetAsync(max_sq, 0, 256, stream) != hipSuccess || hipMemsetAsync(acc, 0, ncols_all * 8, stream) != hipSuccess)
       return ac_fail(AC_ELAUNCH, "ac_pair_min_dist: hipMemsetAsync failed");
-    if ((rc = ac_pair_fixed_shift(max_sq, nk, shift, stream_))) return rc;      // max_sq is in scaled units by now
+    if ((rc = ac_max_f32(sk, nk * P, max_sq, stream_))) return rc;
+    if (!same && (rc = ac_max_f32(sq, nq * P, max_sq, stream_))) return rc;
+    if ((rc = ac_pair_fixed_shift(max_sq, nk, shift, stream_))) return rc;
   } else {
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((ncols_all + 255) / 256 < 4096 ? (ncols_all + 255) / 256 : 4096)),
                        dim3(256), 0, stream, reinterpret_cast<unsigned*>(acc), ncols_all, 0x7f800000u);
@@ -446,8 +366,8 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096)),
                        dim3(256), 0, stream, minbuf, cells, 0x7f800000u);
     // whole square in one launch -> C = C^T
-    EpiPairMin epi{minbuf, minbuf, M, N, P, 6.f * (float)dist_chunks(D), same && chunk == nq, false};
-    rc = launch_pair_min(hk, hq + (size_t)q0 * P * rb, M, N, dist_k(D), epi, stream);
+    EpiPairMin epi{sk, sq + q0 * P, minbuf, minbuf, M, N, P, same && chunk == nq, false};
+    rc = launch_pair_min(hk, hq + (size_t)q0 * P * D * 4, M, N, D, epi, stream);
     if (rc) return rc;
     void* acc_q = mean ? static_cast<void*>(acc + q0 * P) : static_cast<void*>(reinterpret_cast<unsigned*>(acc) + q0 * P);
     if ((rc = ac_pair_accumulate(minbuf, nk, N, N, P, reduce, self_offset + q0, shift, acc_q, stream_))) return rc;
@@ -461,23 +381,23 @@ extern "C" int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, in
     AC_REQUIRE(inside || outside, "ac_pair_min_dist: the query block must lie wholly inside or outside the key list");
     count = inside ? nk - 1 : nk;
   }
-  return ac_pair_finalize(acc, (int64_t)ncols_all, reduce, count, shift, scale_exp, w, stream_);
+  return ac_pair_finalize(acc, (int64_t)ncols_all, reduce, count, shift, w, stream_);
 }
 
 // Staged form of the same computation (pack -> min-d2 GEMM -> accumulate -> finalize) for callers that keep
 // the packed operands resident, shard the category over GPUs, or time the MFMA kernel on its own.
-extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, int64_t nk, const void* Zq_hl, int64_t nq, int P, int D,
-                                     uint32_t* minbuf, uint32_t* minbuf_t, int part, int nparts, void* stream) {
-  AC_REQUIRE(Zk_hl && Zq_hl && minbuf, "ac_pair_min_sq_packed: null pointer");
+extern "C" int ac_pair_min_sq_packed(const void* Zk_hl, const float* k_sq, int64_t nk, const void* Zq_hl,
+                                     const float* q_sq, int64_t nq, int P, int D, uint32_t* minbuf, uint32_t* minbuf_t,
+                                     int part, int nparts, void* stream) {
+  AC_REQUIRE(Zk_hl && k_sq && Zq_hl && q_sq && minbuf, "ac_pair_min_sq_packed: null pointer");
   AC_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "ac_pair_min_sq_packed: bad part %d/%d", part, nparts);
   AC_REQUIRE(nq > 0 && nk > 0 && P > 0 && D > 0 && D % 32 == 0, "ac_pair_min_sq_packed: bad shape");
   AC_REQUIRE((nk * P) <= 0x7fffff00LL && (nq * P) <= 0x7fffff00LL, "ac_pair_min_sq_packed: too many patches");
   const bool same = Zk_hl == Zq_hl && nk == nq;
   AC_REQUIRE(!(same && minbuf_t), "ac_pair_min_sq_packed: keys == queries is the symmetric case; minbuf_t must be NULL");
   AC_REQUIRE(!(minbuf_t && nparts != 1), "ac_pair_min_sq_packed: two-way blocks are not sliced");
-  EpiPairMin epi{minbuf, same ? minbuf : minbuf_t, (int)(nk * P), (int)(nq * P), P, 6.f * (float)dist_chunks(D), same,
-                 minbuf_t != nullptr};
-  return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), dist_k(D), epi, as_stream(stream), part, nparts);
+  EpiPairMin epi{k_sq, q_sq, minbuf, same ? minbuf : minbuf_t, (int)(nk * P), (int)(nq * P), P, same, minbuf_t != nullptr};
+  return launch_pair_min(Zk_hl, Zq_hl, (int)(nk * P), (int)(nq * P), D, epi, as_stream(stream), part, nparts);
 }
 
 // ------------------------------------------- supervised weights: pruned exact nearest neighbour
@@ -545,17 +465,15 @@ struct EpiNNCand {
   }
 };
 
-// hi plane of the DATA groups of a distance operand -> plain fp16 rows [rows][K] (the operand of pass 1)
+// hi plane of an hl32 image -> plain fp16 rows [rows][K] (the operand of pass 1)
 __global__ __launch_bounds__(256) void h16_from_hl32_kernel(const uint8_t* __restrict__ src, int64_t rows, int K,
                                                             uint8_t* __restrict__ dst) {
-  const int64_t groups = (int64_t)K / 32;                         // 128-byte data groups per row
-  const int64_t sgroups = dist_k(K) / 32;                         // ... and group slots per source row
+  const int64_t groups = (int64_t)K / 32;                         // 128-byte hl32 groups per row
   const int64_t total = rows * groups * 4;                        // 16-byte pieces of hi halves
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t g = e >> 2, row = g / groups;
-    const int gi = (int)(g - row * groups), piece = (int)(e & 3);
-    *reinterpret_cast<u32x4*>(dst + g * 64 + piece * 16) =
-        *reinterpret_cast<const u32x4*>(src + (row * sgroups + dist_group_pos(gi)) * 128 + piece * 16);
+    const int64_t g = e >> 2;
+    const int piece = (int)(e & 3);
+    *reinterpret_cast<u32x4*>(dst + g * 64 + piece * 16) = *reinterpret_cast<const u32x4*>(src + g * 128 + piece * 16);
   }
 }
 
@@ -621,12 +539,12 @@ __global__ __launch_bounds__(256) void nn_refine_kernel(const uint8_t* __restric
   }
   if (n == 0) return;
   const int groups = D / 32;
-  const size_t ld = (size_t)dist_k(D) * 4;                         // rows are distance operands (common.h): data group g
-  float av[GPL][32];                                               // sits in group slot dist_group_pos(g)
+  const size_t ld = (size_t)D * 4;
+  float av[GPL][32];
   const uint8_t* a = Zq + (size_t)q * ld;
 #pragma unroll
   for (int u = 0; u < GPL; ++u) {
-    const int g = dist_group_pos(min(lane + 64 * u, groups - 1));
+    const int g = min(lane + 64 * u, groups - 1);
 #pragma unroll
     for (int piece = 0; piece < 4; ++piece) {
       const half8 h = *reinterpret_cast<const half8*>(a + (size_t)g * 128 + piece * 16);
@@ -643,7 +561,7 @@ __global__ __launch_bounds__(256) void nn_refine_kernel(const uint8_t* __restric
     half8 bh[GPL][4], bl[GPL][4];
 #pragma unroll
     for (int u = 0; u < GPL; ++u) {
-      const int g = dist_group_pos(min(lane + 64 * u, groups - 1));
+      const int g = min(lane + 64 * u, groups - 1);
 #pragma unroll
       for (int piece = 0; piece < 4; ++piece) {
         bh[u][piece] = *reinterpret_cast<const half8*>(b + (size_t)g * 128 + piece * 16);
@@ -669,15 +587,15 @@ __global__ __launch_bounds__(256) void nn_refine_kernel(const uint8_t* __restric
   if (lane == 0) best[q] = bestd;
 }
 
-__global__ void nn_finalize_kernel(const double* __restrict__ best, int64_t n, const int* __restrict__ scale_exp, float* __restrict__ w) {
+__global__ void nn_finalize_kernel(const double* __restrict__ best, int64_t n, float* __restrict__ w) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) w[i] = (float)ldexp(sqrt(best[i]), scale_exp ? scale_exp[0] : 0);
+  if (i < n) w[i] = (float)sqrt(best[i]);
 }
 
-extern "C" int ac_nn_finalize(const double* best_d2, int64_t n, const int32_t* scale_exp, float* w, void* stream) {
+extern "C" int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream) {
   AC_REQUIRE(best_d2 && w, "ac_nn_finalize: null pointer");
   if (n <= 0) return AC_OK;
-  hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), best_d2, n, scale_exp, w);
+  hipLaunchKernelGGL(nn_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), best_d2, n, w);
   return ac_check_launch("ac_nn_finalize");
 }
 

@@ -63,19 +63,6 @@ __device__ inline void store_hl32_8(uint8_t* row_base, int k, const float* v) {
   *reinterpret_cast<half8*>(p + 64) = lo;
 }
 
-// ---- distance operand ("hl32d"): an hl32 row with NORM GROUPS.  After every 32 data groups (1024 k values) and after
-// the last one, one extra 128-byte group holds  hi plane = {1, 1, 1, 0, ...},  lo plane = {p1, p2, p3, 0, ...}  with
-// p1 + p2 + p3 = -|row chunk|^2 / 2 exactly (three fp16 terms of the fp32 value).  The three split-fp16 passes of the
-// GEMM multiply hi x lo, lo x hi and hi x hi, so over such a group they add  -|b_c|^2/2,  -|a_c|^2/2  and the constant 3:
-// the MFMA itself turns the running dot product into  -|a - b|^2 / 2  chunk by chunk, and the accumulator stays
-// small for exactly the pairs that decide a minimum (near patches) - the job of round 2's second accumulator, without
-// its registers.  The GEMM kernels see K' = dist_k(K) ordinary k values.
-constexpr int DIST_CHUNK_GROUPS = 32;                    // data groups (of 32 k values) per norm group
-__host__ __device__ inline int dist_chunks(int K) { return (K / 32 + DIST_CHUNK_GROUPS - 1) / DIST_CHUNK_GROUPS; }
-__host__ __device__ inline int dist_k(int K) { return K + 32 * dist_chunks(K); }
-__host__ __device__ inline int dist_group_pos(int g) { return g + g / DIST_CHUNK_GROUPS; }   // data group g -> group slot
-constexpr float DIST_NORM_LIMIT = 65504.f;               // |row chunk|^2 / 2 must fit fp16's range
-
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

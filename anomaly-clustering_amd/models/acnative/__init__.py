@@ -53,16 +53,13 @@ SIGNATURES = {
     "ac_adaptive_avg_pool_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "ac_pair_min_dist_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
     "ac_pair_min_dist": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
-    "ac_dist_row_bytes": (_sz, [_i]),
-    "ac_pack_dist": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp, _i, _vp]),
-    "ac_dist_scale": (_i, [_vp, _vp, _vp]),
-    "ac_pair_min_sq_packed": (_i, [_vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ac_pair_min_sq_packed": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ac_fill_u32": (_i, [_vp, _i64, _c.c_uint32, _vp]),
     "ac_fill_u64": (_i, [_vp, _i64, _c.c_uint64, _vp]),
     "ac_max_f32": (_i, [_vp, _i64, _vp, _vp]),
     "ac_pair_fixed_shift": (_i, [_vp, _i64, _vp, _vp]),
     "ac_pair_accumulate": (_i, [_vp, _i64, _i64, _i64, _i, _i, _i64, _vp, _vp, _vp]),
-    "ac_pair_finalize": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp, _vp]),
+    "ac_pair_finalize": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "ac_h16_from_hl32": (_i, [_vp, _i64, _i, _vp, _vp]),
     "ac_nn_slack": (_i, [_vp, _vp, _vp, _vp]),
     "ac_nn_candidates": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
@@ -70,7 +67,7 @@ SIGNATURES = {
     "ac_nn_overflow_compact": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "ac_gather_rows": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "ac_nn_scatter_exhaustive": (_i, [_vp, _vp, _i64, _vp, _vp]),
-    "ac_nn_finalize": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "ac_nn_finalize": (_i, [_vp, _i64, _vp, _vp]),
     "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
@@ -384,16 +381,8 @@ INF_BITS = 0x7f800000
 F64_INF_BITS = 0x7ff0000000000000
 
 
-def dist_row_bytes(D):
-    """Bytes of one row of the distance operand (include/ac_hip.h: hl32 + one norm group per 1024 columns)."""
-    n = int(lib().ac_dist_row_bytes(int(D)))
-    if n == 0:
-        raise ValueError("D=%d must be a positive multiple of 32" % D)
-    return n
-
-
 class Packed:
-    """Distance operands of a block of images: hl uint8 [n*P, dist_row_bytes(D)], sq fp32 [n*P] (squared row norms)."""
+    """hl32 image of a block of images: hl uint8 [n*P, D*4], sq fp32 [n*P] (squared row norms)."""
 
     def __init__(self, hl, sq, n, P, D):
         self.hl, self.sq, self.n, self.P, self.D = hl, sq, n, P, D
@@ -408,36 +397,18 @@ class Packed:
 
     @staticmethod
     def empty(n, P, D, device):
-        return Packed(torch.empty((n * P, dist_row_bytes(D)), dtype=torch.uint8, device=device),
+        return Packed(torch.empty((n * P, D * 4), dtype=torch.uint8, device=device),
                       torch.empty((n * P,), dtype=torch.float32, device=device), n, P, D)
 
 
-def pack_images(Z, scale=None):
-    """Z fp32 [n, P, D] -> Packed (one pass: distance operands - split-fp16 image with norm groups - + squared norms).
-    scale: None = the first, unscaled pass; a device int32 [1] from dist_scale() = values times 2^-scale."""
-    p = _dev(Z, torch.float32, "Z")
+def pack_images(Z):
+    """Z fp32 [n, P, D] -> Packed (one pass: split-fp16 image + squared norms)."""
+    _dev(Z, torch.float32, "Z")
     n, P, D = Z.shape
-    pk = Packed.empty(n, P, D, Z.device)
-    if n:
-        _check(lib().ac_pack_dist(p, n * P, D, D, pk.hl.data_ptr(), pk.sq.data_ptr(),
-                                  _dev(scale, torch.int32, "scale") if scale is not None else None, 0, _stream()))
-    return pk
-
-
-def dist_scale(max_sq_t):
-    """The power-of-two scale of a distance computation from the largest squared norm of ALL its rows (fp32 [1] on the
-    device, MAX-reduced over the ranks): int32 [1] e >= 0 (0 for ordinary features); max_sq_t is rewritten in scaled units."""
-    e = torch.empty(1, dtype=torch.int32, device=max_sq_t.device)
-    _check(lib().ac_dist_scale(_dev(max_sq_t, torch.float32, "max_sq"), e.data_ptr(), _stream()))
-    return e
-
-
-def repack_scaled(pk, Z, scale):
-    """Second, conditional pass of the packing: a no-op on the device when scale == 0, else pk is rewritten from
-    Z * 2^-scale.  No host read either way."""
-    if pk.n:
-        _check(lib().ac_pack_dist(_dev(Z, torch.float32, "Z"), pk.n * pk.P, pk.D, pk.D, pk.hl.data_ptr(), pk.sq.data_ptr(),
-                                  _dev(scale, torch.int32, "scale"), 1, _stream()))
+    if n == 0:
+        return Packed.empty(0, P, D, Z.device)
+    hl, sq = pack_hl32(Z.reshape(n * P, D), want_sqnorm=True)
+    return Packed(hl, sq, n, P, D)
 
 
 def max_sq(packed_list, device):
@@ -505,7 +476,8 @@ def pair_block(keys, queries, two_way=False, part=0, nparts=1):
     minbuf = filled((nk, nq * P), torch.int32, dev, INF_BITS)
     minbuf_t = filled((nq, nk * P), torch.int32, dev, INF_BITS) if two_way else None
     ev0, ev1 = _event_pair()
-    _check(lib().ac_pair_min_sq_packed(keys.hl.data_ptr(), nk, queries.hl.data_ptr(), nq, P, D, minbuf.data_ptr(),
+    _check(lib().ac_pair_min_sq_packed(keys.hl.data_ptr(), keys.sq.data_ptr(), nk, queries.hl.data_ptr(),
+                                       queries.sq.data_ptr(), nq, P, D, minbuf.data_ptr(),
                                        minbuf_t.data_ptr() if two_way else None, part, nparts, _stream()))
     if ev0 is not None:
         ev1.record()
@@ -528,14 +500,13 @@ def pair_accumulate(minbuf, P, reduce, self_first, shift, acc):
                                     shift.data_ptr() if shift is not None else None, acc.data_ptr(), _stream()))
 
 
-def pair_finalize(acc, P, reduce, count, shift, scale=None):
-    """acc [n*P] -> w fp32 [n, P] (times 2^scale when the operands were packed scaled)."""
+def pair_finalize(acc, P, reduce, count, shift):
+    """acc [n*P] -> w fp32 [n, P]."""
     ncols = acc.numel()
     w = torch.empty((ncols // P, P), dtype=torch.float32, device=acc.device)
     if ncols:
         _check(lib().ac_pair_finalize(acc.data_ptr(), ncols, reduce, int(count),
-                                      shift.data_ptr() if shift is not None else None,
-                                      scale.data_ptr() if scale is not None else None, w.data_ptr(), _stream()))
+                                      shift.data_ptr() if shift is not None else None, w.data_ptr(), _stream()))
     return w
 
 
@@ -548,7 +519,6 @@ def pair_min_dist_staged(Zq, Zk, reduce, self_offset=0, minbuf_budget=1 << 30):
     if Zk.shape[1:] != Zq.shape[1:]:
         raise ValueError("Zq / Zk patch shapes differ: %s vs %s" % (tuple(Zq.shape), tuple(Zk.shape)))
     keys = pack_images(Zk)
-    own_queries = False
     if pq == pk and nq == nk:
         queries = keys
     elif pk <= pq < pk + Zk.numel() * 4 and (pq - pk) % (P * D * 4) == 0 and pq + Zq.numel() * 4 <= pk + Zk.numel() * 4:
@@ -556,14 +526,8 @@ def pair_min_dist_staged(Zq, Zk, reduce, self_offset=0, minbuf_budget=1 << 30):
         queries = keys.slice(first, first + nq)
     else:
         queries = pack_images(Zq)
-        own_queries = True
     mean = reduce == REDUCE_MEAN_OTHERS
-    m = max_sq([keys, queries] if own_queries else [keys], Zq.device)
-    scale = dist_scale(m)                                     # 0 for ordinary features: the second passes return at once
-    repack_scaled(keys, Zk, scale)
-    if own_queries:
-        repack_scaled(queries, Zq, scale)
-    shift = fixed_shift(m, nk) if mean else None
+    shift = fixed_shift(max_sq([keys] if queries is keys else [keys, queries], Zq.device), nk) if mean else None
     acc = new_acc(nq * P, reduce, Zq.device)
     chunk = max(1, min(nq, minbuf_budget // (nk * P * 4)))
     for q0 in range(0, nq, chunk):
@@ -572,7 +536,7 @@ def pair_min_dist_staged(Zq, Zk, reduce, self_offset=0, minbuf_budget=1 << 30):
         mb = pair_block(keys, qs)
         pair_accumulate(mb, P, reduce, self_offset + q0, shift, acc[q0 * P:(q0 + qn) * P])
     inside = 0 <= self_offset and self_offset + nq <= nk
-    return pair_finalize(acc, P, reduce, nk - 1 if (mean and inside) else nk, shift, scale)
+    return pair_finalize(acc, P, reduce, nk - 1 if (mean and inside) else nk, shift)
 
 
 def pair_min_sq_part(Z, part=0, nparts=1):
@@ -673,9 +637,9 @@ class OverflowQueries:
         self.packed = None
         if self.n_rows:
             rows = -(-self.n_rows // P) * P                    # the kernel's query axis comes in whole "images" of P rows
-            hl = torch.empty((rows, dist_row_bytes(D)), dtype=torch.uint8, device=dev)
+            hl = torch.empty((rows, D * 4), dtype=torch.uint8, device=dev)
             sq = torch.empty((rows,), dtype=torch.float32, device=dev)
-            _check(lib().ac_gather_rows(queries.hl.data_ptr(), dist_row_bytes(D), self.idx.data_ptr(), self.n_rows, rows, hl.data_ptr(), _stream()))
+            _check(lib().ac_gather_rows(queries.hl.data_ptr(), D * 4, self.idx.data_ptr(), self.n_rows, rows, hl.data_ptr(), _stream()))
             _check(lib().ac_gather_rows(queries.sq.data_ptr(), 4, self.idx.data_ptr(), self.n_rows, rows, sq.data_ptr(), _stream()))
             self.packed = Packed(hl, sq, rows // P, P, D)
             self.acc = new_acc(rows, REDUCE_MIN_ALL, dev)
@@ -700,11 +664,10 @@ def nn_any_overflow(state):
     return bool(int(state.overflow.item()))
 
 
-def nn_finalize(state, P, scale=None):
+def nn_finalize(state, P):
     w = torch.empty((state.n // P, P), dtype=torch.float32, device=state.best.device)
     if state.n:
-        _check(lib().ac_nn_finalize(state.best.data_ptr(), state.n, scale.data_ptr() if scale is not None else None,
-                                    w.data_ptr(), _stream()))
+        _check(lib().ac_nn_finalize(state.best.data_ptr(), state.n, w.data_ptr(), _stream()))
     return w
 
 

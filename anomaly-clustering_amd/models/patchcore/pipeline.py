@@ -133,15 +133,6 @@ class HipOps:
     def pack(self, Z):
         return self.acnative.pack_images(Z)
 
-    def rescale(self, pairs, max_sq_t):
-        """pairs: [(packed, Z)] of THIS rank; max_sq_t: the largest squared norm of every row of the computation (all
-        ranks).  Returns the device scale exponent e (0 for ordinary features) and rewrites max_sq_t in scaled units; when
-        e > 0 the packed blocks are rewritten from Z * 2^-e on the device (no host read either way)."""
-        scale = self.acnative.dist_scale(max_sq_t)
-        for pk, Z in pairs:
-            self.acnative.repack_scaled(pk, Z, scale)
-        return scale
-
     def empty_packed(self, n, like):
         return self.acnative.Packed.empty(n, like.P, like.D, like.hl.device)
 
@@ -160,8 +151,8 @@ class HipOps:
     def pair_accumulate(self, minbuf, P, reduce, self_first, shift, acc):
         self.acnative.pair_accumulate(minbuf, P, reduce, self_first, shift, acc)
 
-    def pair_finalize(self, acc, P, reduce, count, shift, scale=None):
-        return self.acnative.pair_finalize(acc, P, reduce, count, shift, scale)
+    def pair_finalize(self, acc, P, reduce, count, shift):
+        return self.acnative.pair_finalize(acc, P, reduce, count, shift)
 
     # ---- pruned exact nearest neighbour of the supervised mode
     nn_prune = True
@@ -185,8 +176,8 @@ class HipOps:
     def nn_overflow_queries(self, state, queries):
         return self.acnative.OverflowQueries(state, queries)
 
-    def nn_finalize(self, state, P, scale=None):
-        return self.acnative.nn_finalize(state, P, scale)
+    def nn_finalize(self, state, P):
+        return self.acnative.nn_finalize(state, P)
 
     def alpha_softmax(self, w, tau, k):
         return self.acnative.alpha_softmax(w, tau, k)
@@ -257,8 +248,7 @@ class _Ring:
         self.last = last_step
         # bytes of one receive buffer from the SHAPE (hl32 row + its norm), not from the local tensors: a rank with an
         # empty shard must arrive at the same depth as the others
-        row_bytes = local.hl.shape[1] * local.hl.element_size() if local.hl.dim() == 2 else local.D * 4
-        per_buffer = max(1, (row_bytes + 4) * local.P * self.cap)
+        per_buffer = max(1, (local.D * 4 + 4) * local.P * self.cap)
         self.depth = max(2, min(max(last_step, 1), remote_bytes // per_buffer))
         self.bufs = [None] * self.depth
         self.pending = {}
@@ -310,45 +300,33 @@ def _slice_global(pk, base, rng):
     return pk.slice(rng[0] - base, rng[1] - base)
 
 
-def _rescale(ops, pairs, max_sq_t):
-    """The category-wide power-of-two scale of the distance operands (HipOps.rescale); compute seams without it (the
-    CPU stand-in of the tests) work unscaled."""
-    fn = getattr(ops, "rescale", None)
-    return fn(pairs, max_sq_t) if fn is not None else None
-
-
-def _finalize(ops, acc, P, reduce, count, shift, scale):
-    return ops.pair_finalize(acc, P, reduce, count, shift) if scale is None else ops.pair_finalize(acc, P, reduce, count, shift, scale)
-
-
 def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto",
-                               remote_bytes=REMOTE_BYTES, Z_loc=None):
-    """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard).  Z_loc: the embeddings pk_loc
-    was packed from (for the rare re-pack at a power-of-two scale, see HipOps.rescale)."""
+                               remote_bytes=REMOTE_BYTES):
+    """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard)."""
     n = bounds[-1][1]
     lo, hi = bounds[rank]
     P = pk_loc.P
     counts = [b - a for a, b in bounds]
     if schedule == "auto":
         schedule = "ring"
-    m = ops.max_sq([pk_loc], device)
-    if world > 1:
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-    scale = _rescale(ops, [(pk_loc, Z_loc)], m) if Z_loc is not None else None     # before any shard leaves the rank
-    shift = ops.fixed_shift(m, n)
     if schedule == "slices":
         rows = [c * P for c in counts]
         hl = all_gather_rows(pk_loc.hl, rows, group)
         sq = all_gather_rows(pk_loc.sq, rows, group)
         pk_all = type(pk_loc)(hl, sq, n, P, pk_loc.D)
+        shift = ops.fixed_shift(ops.max_sq([pk_all], device), n)
         minbuf = ops.pair_block(pk_all, pk_all, part=rank, nparts=world)          # [N, N*P], +inf outside the slice
         if world > 1:
             mf = minbuf.view(torch.float32)
             dist.all_reduce(mf, op=dist.ReduceOp.MIN, group=group)
         acc = ops.new_acc((hi - lo) * P, MEAN, device)
         ops.pair_accumulate(minbuf[:, lo * P: hi * P], P, MEAN, lo, shift, acc)
-        return _finalize(ops, acc, P, MEAN, n - 1, shift, scale)
+        return ops.pair_finalize(acc, P, MEAN, n - 1, shift)
 
+    m = ops.max_sq([pk_loc], device)
+    if world > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    shift = ops.fixed_shift(m, n)
     acc = ops.new_acc(n * P, MEAN, device)                 # sums for EVERY image: remote queries' parts too
     c = block_images(P, budget)
     ring = _Ring(ops, pk_loc, counts, rank, world, group, last_step=world // 2, remote_bytes=remote_bytes)
@@ -377,11 +355,11 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
                 ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[a[0] * P: a[1] * P])    # keys B, queries A
     if world > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-    return _finalize(ops, acc[lo * P: hi * P], P, MEAN, n - 1, shift, scale)
+    return ops.pair_finalize(acc[lo * P: hi * P], P, MEAN, n - 1, shift)
 
 
 def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
-                             remote_bytes=REMOTE_BYTES, prune=True, Z_loc=None, bank_loc=None):
+                             remote_bytes=REMOTE_BYTES, prune=True):
     """w fp32 [n_loc, P]: min over every bank image (utils.py:230-237 for every i of the shard).  The bank
     shards go round the ring.  Default: the pruned EXACT nearest-neighbour search - per shard one MFMA launch on
     the fp16 high halves keeps, for every query patch, the bank patches within a proven error bound of the
@@ -393,13 +371,8 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     n_loc = pk_loc.n
     counts = [b - a for a, b in bank_bounds]
     m = sum(counts)
-    # one power-of-two scale for bank and queries (0 on ordinary features), from the largest norm of the whole run
-    mall = ops.max_sq([pk_bank_loc, pk_loc], device)
-    if world > 1:
-        dist.all_reduce(mall, op=dist.ReduceOp.MAX, group=group)
-    scale = _rescale(ops, [(pk_loc, Z_loc), (pk_bank_loc, bank_loc)], mall) if (Z_loc is not None and bank_loc is not None) else None
     if prune and getattr(ops, "nn_prune", False) and pk_loc.D % 64 == 0:
-        mk, mq = ops.max_sq([pk_bank_loc], device), ops.max_sq([pk_loc], device)     # of the operands as packed (scaled)
+        mk, mq = ops.max_sq([pk_bank_loc], device), ops.max_sq([pk_loc], device)
         if world > 1:                               # the bound must hold for every (query, bank patch) pair of the run
             dist.all_reduce(mk, op=dist.ReduceOp.MAX, group=group)
             dist.all_reduce(mq, op=dist.ReduceOp.MAX, group=group)
@@ -426,7 +399,7 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
             for k in range(world):
                 over.scan(pk_bank_loc if k == 0 else ring.get(k), budget)
             over.commit(state)
-        return ops.nn_finalize(state, P) if scale is None else ops.nn_finalize(state, P, scale)
+        return ops.nn_finalize(state, P)
     acc = ops.new_acc(n_loc * P, MIN, device)
     ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
     c = block_images(P, budget)
@@ -439,7 +412,7 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
             for k0, k1 in _subranges(0, keys.n, c):
                 mb = ops.pair_block(keys.slice(k0, k1), Q)
                 ops.pair_accumulate(mb, P, MIN, NO_SELF, None, acc[q0 * P: q1 * P])
-    return _finalize(ops, acc, P, MIN, m, None, scale)
+    return ops.pair_finalize(acc, P, MIN, m, None)
 
 
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
@@ -484,11 +457,11 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         blo, bhi = bb[rank]
         bank_loc = ops.embed(train_images[sel[blo:bhi]])
         w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget,
-                                         remote_bytes, prune, Z_loc=Z_loc, bank_loc=bank_loc)
+                                         remote_bytes, prune)
         del bank_loc
     elif supervised == "unsupervised":
         w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule,
-                                           remote_bytes, Z_loc=Z_loc)
+                                           remote_bytes)
     else:                                                              # "average" (main.py:290-291)
         w_loc = None
     mark("pair_min_dist", t0)

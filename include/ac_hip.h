@@ -66,24 +66,6 @@ int ac_set_gemm_policy(int policy);
 int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_ld, void* dst_hl32,
                  float* row_sqnorm, void* stream);
 
-/* The DISTANCE OPERAND of the all-pairs kernel (Weight_Distance_*, utils.py:222-237): an hl32 row of
- * ac_dist_row_bytes(K) = (K + 32 * ceil(K / 1024)) * 4 bytes - after every 32 data groups (and after the last) one extra
- * 128-byte NORM GROUP: hi plane {1, 1, 1, 0...}, lo plane {p1, p2, p3, 0...}, p1 + p2 + p3 = -|row chunk|^2 / 2 exactly.
- * The GEMM's three split-fp16 passes (hi x lo, lo x hi, hi x hi) turn such a group into "- |b_c|^2/2 - |a_c|^2/2 + 3", so
- * its accumulator holds 3 * groups - |a - b|^2 / 2 chunk by chunk and stays small for near pairs: fp32-grade distances
- * from ONE accumulator (csrc/common.h).  row_sqnorm (nullable): fp32 [rows], squared norms of the rows AS PACKED.
- * A chunk's half squared norm must fit fp16 (< 65504; a standardised feature row has ~ 4e2).  For anything larger the
- * whole computation is scaled by a power of two, on the device, without a host read:
- *   ac_pack_dist(scale_exp = NULL)            first pass, unscaled; row_sqnorm -> ac_max_f32 -> max_sq (all ranks: MAX)
- *   ac_dist_scale(max_sq, scale_exp)          e = smallest e >= 0 with max_sq * 4^-e / 2 < 60000; max_sq *= 4^-e
- *   ac_pack_dist(scale_exp, only_if_scaled=1) second pass: returns at once when e == 0 (the ordinary case), else rewrites
- *                                             operands and row_sqnorm from the values * 2^-e (exact)
- * and ac_pair_finalize / ac_nn_finalize multiply the distances by 2^e again. */
-size_t ac_dist_row_bytes(int K);
-int ac_pack_dist(const float* src, int64_t rows, int K, int64_t src_ld, void* dst, float* row_sqnorm,
-                 const int32_t* scale_exp, int only_if_scaled, void* stream);
-int ac_dist_scale(float* max_sq, int32_t* scale_exp, void* stream);
-
 /* ------------------------------------------------------------- input pipeline */
 
 /* The image transform of the MVTec dataset (models/patchcore/datasets/mvtec.py:74-81), batched:
@@ -202,7 +184,7 @@ int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, i
  * blocks that fit a memory budget, shard it over GPUs (models/patchcore/pipeline.py), or time the MFMA
  * kernel alone.  The reference's per-pair loop being replaced is utils.py:222-237.
  *
- *   ac_pack_dist(Z, rows = n*P, K = D, ...) / ac_dist_scale (above)       -> Z_hl (distance operands), sq, scale_exp
+ *   ac_pack_hl32(Z, rows = n*P, K = D, ..., row_sqnorm)            -> Z_hl, sq
  *
  *   ac_pair_min_sq_packed: ONE launch of the MFMA GEMM with the fused min, on the rectangle
  *       keys (nk images) x queries (nq images):
@@ -229,22 +211,23 @@ int ac_pair_min_dist(const float* Zq, int64_t nq, const float* Zk, int64_t nk, i
  *                    (self_first = index, within this block's key rows, of the key image that IS the first
  *                    query image; any value outside [-(ncols/P), nk) skips nothing);  preset acc to 0.
  *       MIN_ALL:     acc uint32 [ncols] = min(acc, min_j minbuf[j][col]);               preset acc to +inf bits.
- *   ac_pair_finalize: w = (float)(acc * 2^-shift / count)  or  sqrt(acc as float), times 2^scale_exp.  count = number
- *       of key images that entered the mean (N - 1). */
-int ac_pair_min_sq_packed(const void* Zk_dist, int64_t nk, const void* Zq_dist, int64_t nq, int P, int D,
-                          uint32_t* minbuf, uint32_t* minbuf_t, int part, int nparts, void* stream);
+ *   ac_pair_finalize: w = (float)(acc * 2^-shift / count)  or  sqrt(acc as float).  count = number of key
+ *       images that entered the mean (N - 1). */
+int ac_pair_min_sq_packed(const void* Zk_hl32, const float* k_sqnorm, int64_t nk, const void* Zq_hl32,
+                          const float* q_sqnorm, int64_t nq, int P, int D, uint32_t* minbuf, uint32_t* minbuf_t,
+                          int part, int nparts, void* stream);
 int ac_fill_u32(uint32_t* dst, int64_t count, uint32_t value, void* stream);   /* presets: +inf bits 0x7f800000, zeros */
 int ac_fill_u64(uint64_t* dst, int64_t count, uint64_t value, void* stream);   /* int64 sums (0), float64 +inf bits */
 int ac_max_f32(const float* x, int64_t n, float* max_out, void* stream);
 int ac_pair_fixed_shift(const float* max_sq, int64_t n_keys, int32_t* shift, void* stream);
 int ac_pair_accumulate(const uint32_t* minbuf, int64_t nk, int64_t ld, int64_t ncols, int P, int reduce,
                        int64_t self_first, const int32_t* shift, void* acc, void* stream);
-int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift,
-                     const int32_t* scale_exp /* nullable = 0 */, float* w, void* stream);
+int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, const int32_t* shift, float* w,
+                     void* stream);
 
 /* Supervised weights as an EXACT pruned nearest-neighbour search (utils.py:230-237: the min runs over every patch of
  * the normal-image bank, so only the nearest bank patch of each query patch needs an exact distance):
- *   ac_h16_from_hl32: the hi plane of the data groups of a distance operand as plain fp16 rows [rows][K] (K % 64 == 0).
+ *   ac_h16_from_hl32: the hi plane of an hl32 image as plain fp16 rows [rows][K] (K % 64 == 0).
  *   ac_nn_slack:      slack (device float [3]): the candidate window of a query a is slack[0] * |a| + slack[1] = 2 delta(a),
  *                     delta(a) = the bound on |d~2 - d2| of pass 1 for that query, from the largest squared norms of
  *                     the two sets (ac_max_f32).  slack[2] != 0: a norm is outside the range in which the fp16 high
@@ -255,7 +238,7 @@ int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, 
  *                     +inf) and appends to cand[q][.] every key row with d~2 <= running minimum + slack; cand_count
  *                     [q] counts them (the caller zeroes it per key set; rows beyond `cap` are counted, not stored).
  *   ac_nn_refine:     pass 2: best_d2[q] = min(best_d2[q], sum_k (q_k - key_k)^2) in fp64 on the split values of the
- *                     distance operands' data groups, over the stored candidates.  A query whose list was longer than cap
+ *                     hl32 images, over the stored candidates.  A query whose list was longer than cap
  *                     (cand_count[q] > cap) is SKIPPED, overflow_flag (int32 [1]) set and overflow_rows[q] (int32
  *                     [nq_rows], may be NULL; sticky across key sets, the caller zeroes it once per search) set: the
  *                     caller measures those queries against the WHOLE bank with the exhaustive kernel
@@ -268,7 +251,7 @@ int ac_pair_finalize(const void* acc, int64_t ncols, int reduce, int64_t count, 
  *                     copy of the overflowed queries (hl32 rows and squared norms), padded to whole images.
  *   ac_nn_scatter_exhaustive: best_d2[idx[i]] = (double) of the exhaustive kernel's min d2 (uint32 float bits) of
  *                     compact query i: those queries equal the un-pruned path bit for bit.
- *   ac_nn_finalize:   w = (float)sqrt(best_d2) * 2^scale_exp.
+ *   ac_nn_finalize:   w = (float)sqrt(best_d2).
  * The true nearest neighbour always survives pass 1 (proof in csrc/alpha.hip), whatever the order of the tiles. */
 int ac_h16_from_hl32(const void* hl32, int64_t rows, int K, void* dst_h16, void* stream);
 int ac_nn_slack(const float* max_sq_keys, const float* max_sq_queries, float* slack, void* stream);
@@ -282,7 +265,7 @@ int ac_nn_overflow_compact(const int32_t* overflow_rows, int64_t n, int32_t* idx
 int ac_gather_rows(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n_idx, int64_t n_rows, void* dst,
                    void* stream);
 int ac_nn_scatter_exhaustive(const uint32_t* acc_bits, const int32_t* idx, int64_t n, double* best_d2, void* stream);
-int ac_nn_finalize(const double* best_d2, int64_t n, const int32_t* scale_exp /* nullable = 0 */, float* w, void* stream);
+int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream);
 
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
  *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;

@@ -86,12 +86,9 @@ def test_argument_validation_of_the_round2_entry_points():
     assert lib.ac_ward_workspace_bytes(10000) >= 8 * 10000 * 10000
     assert lib.ac_pair_accumulate(ctypes.c_void_p(16), 4, 2, 8, 4, 0, 0, None, ctypes.c_void_p(16), None) == 1   # ld < ncols
     assert lib.ac_pair_accumulate(ctypes.c_void_p(16), 4, 8, 8, 4, 0, 0, None, ctypes.c_void_p(16), None) == 1   # mean needs shift
-    assert lib.ac_pair_min_sq_packed(ctypes.c_void_p(16), 2, ctypes.c_void_p(16), 2, 8, 64,
+    assert lib.ac_pair_min_sq_packed(ctypes.c_void_p(16), ctypes.c_void_p(16), 2, ctypes.c_void_p(16), ctypes.c_void_p(16), 2, 8, 64,
                                      ctypes.c_void_p(16), ctypes.c_void_p(32), 0, 1, None) == 1                   # symmetric + minbuf_t
     assert b"symmetric case" in lib.ac_last_error()
-    # the distance operand: one 128-byte norm group per 32 data groups (1024 columns), and after the last one
-    assert lib.ac_dist_row_bytes(4096) == (4096 + 4 * 32) * 4 and lib.ac_dist_row_bytes(64) == (64 + 32) * 4
-    assert lib.ac_dist_row_bytes(1056) == (1056 + 2 * 32) * 4 and lib.ac_dist_row_bytes(48) == 0
     assert lib.ac_set_gemm_policy(77) == 1 and lib.ac_set_gemm_policy(0) == 0
 
 

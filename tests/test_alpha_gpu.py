@@ -268,42 +268,28 @@ def test_pruned_search_re_measures_queries_whose_candidate_lists_overflow(dev):
     assert (got - ref).abs().max().item() <= 2e-5
 
 
-def test_large_features_are_scaled_by_a_power_of_two(dev):
-    """The distance operand stores -|row chunk|^2 / 2 in fp16 pieces, so a chunk's half squared norm must stay below 65504
-    (standardised features: ~ 4e2).  Larger features are handled on the device, without a host read: the category-wide
-    scale e (ac_dist_scale, from the MAX-reduced largest norm) re-packs everything times 2^-e (exact) and the finalize
-    kernels multiply the distances by 2^e again.  Features times 8000 (|row| ~ 80 000, far beyond fp16): unsupervised and
-    supervised w against the float64 brute force on the same values, relative 1e-6 (fp32 rounding of w), and
-    w(2^13 Z) == 2^13 w(Z) to the bit (a power-of-two factor changes nothing but exponents)."""
+def test_pruned_search_leaves_norms_beyond_fp16_to_the_exhaustive_kernel(dev):
+    """The error bound of the first pass needs finite fp16 high halves, which |row| < 65504 guarantees.  Rows with a
+    larger norm (here every element is still inside fp16's range: D = 256 values of ~5000 give |row| ~ 80 000) flip
+    ac_nn_slack's range flag: every query is treated as overflowed and the exhaustive split-fp16 blocks decide - the
+    answer is prune=False's, bit for bit, and finite (the pruned path used to return silently wrong
+    minima once a high half became inf)."""
     import acnative
     from patchcore.pipeline import run_category
     Zq, _ = clustered_embeddings(3, 100, 256, 2, salt=85)
     Zk, _ = clustered_embeddings(4, 100, 256, 1, salt=86)
-    big_q, big_k = torch.from_numpy(Zq * 8000.0).to(dev), torch.from_numpy(Zk * 8000.0).to(dev)
-    pk = acnative.pack_images(big_k)
-    m = acnative.max_sq([pk], dev)
-    assert float(m.sqrt().item()) > 65504.0
-    e = acnative.dist_scale(m)
-    assert int(e.item()) >= 8 and float(m.item()) * 0.5 < 60000.0            # max_sq comes back in scaled units
-    for mode, kw in (("unsupervised", {}), ("supervised", {"train_images": big_k, "train_ratio": 2.0})):
-        got = run_category(_IdentityOps(), big_q, mode, tau=1.0, **kw)["w_loc"].double().cpu().numpy()
-        a = _split_values(big_q)
-        b = _split_values(big_k) if mode == "supervised" else a
-        truth = np.zeros((3, 100))
-        for i in range(3):
-            cols = []
-            for j in range(b.shape[0]):
-                if mode == "unsupervised" and j == i:
-                    continue
-                d2 = (a[i] * a[i]).sum(1)[:, None] + (b[j] * b[j]).sum(1)[None, :] - 2.0 * a[i] @ b[j].T
-                cols.append(d2.clamp_min(0).sqrt().min(1)[0])
-            cols = torch.stack(cols, 1)
-            truth[i] = (cols.mean(1) if mode == "unsupervised" else cols.min(1)[0]).cpu().numpy()
-        np.testing.assert_allclose(got, truth, rtol=2e-6, atol=0)
-    small = run_category(_IdentityOps(), torch.from_numpy(Zq).to(dev), "unsupervised", tau=1.0)["w_loc"]
-    scaled = run_category(_IdentityOps(), torch.from_numpy(Zq * 8192.0).to(dev), "unsupervised", tau=1.0)["w_loc"]
-    assert torch.equal(scaled, small * 8192.0)
-    assert int(acnative.dist_scale(acnative.max_sq([acnative.pack_images(torch.from_numpy(Zq).to(dev))], dev)).item()) == 0
+    tq, tk = torch.from_numpy(Zq * 8000.0).to(dev), torch.from_numpy(Zk * 8000.0).to(dev)
+    pk = acnative.pack_images(tk)
+    assert float(acnative.max_sq([pk], dev).sqrt().item()) > 65504.0 and float(tk.abs().max().item()) < 65504.0
+    s = acnative.nn_slack(acnative.max_sq([pk], dev), acnative.max_sq([acnative.pack_images(tq)], dev))
+    assert float(s[2].item()) == 1.0
+    pruned = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0)["w_loc"]
+    exhaustive = run_category(_IdentityOps(), tq, "supervised", tau=1.0, train_images=tk, train_ratio=2.0, prune=False)["w_loc"]
+    assert torch.isfinite(pruned).all() and torch.equal(pruned, exhaustive)
+    # in range: the flag stays clear
+    s = acnative.nn_slack(acnative.max_sq([acnative.pack_images(torch.from_numpy(Zk).to(dev))], dev),
+                          acnative.max_sq([acnative.pack_images(torch.from_numpy(Zq).to(dev))], dev))
+    assert float(s[2].item()) == 0.0
 
 
 def test_fixed_point_scale_follows_the_data(dev):
