@@ -322,8 +322,11 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
 }
 
 template <class Epi, int NT = 8, bool FLUSH = false, int WN = 2, bool PLAIN = false>
+#ifndef AC_G5_GROUP_M
+#define AC_G5_GROUP_M 4          // L2 window of the linear-layer launches, in tile rows (same-box A/B knob)
+#endif
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                  int group_m = 4, int part = 0, int nparts = 1) {
+                  int group_m = AC_G5_GROUP_M, int part = 0, int nparts = 1) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl5: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl5: bad part %d/%d", part, nparts);
