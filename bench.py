@@ -464,7 +464,9 @@ def main():
                         "passes named in traffic_source (rank 0's launches). Supervised workloads run the PRUNED exact "
                         "search: the timed launch does ONE fp16 pass over every (test, bank) pair (a third of the issued "
                         "work) and the few surviving candidates are re-measured exactly by a separate small kernel, so "
-                        "the same algorithmic FLOP count is resolved with 1x issued work and frac <= 1"}
+                        "the same algorithmic FLOP count is resolved with 1x issued work and frac <= 1. Same-box reference: "
+                        "the vendor library's plain fp16 GEMM reaches 0.50-0.56 of this peak at its best shapes "
+                        "(profiles/r03_vendor_reference.txt; DESIGN.md section 4)"}
     elif vit_events:
         ms = [e0.elapsed_time(e1) for (e0, e1, _) in vit_events]
         imgs = sum(n for (_, _, n) in vit_events)
