@@ -254,8 +254,14 @@ class _Ring:
         self.pending = {}
         self.stage = world > 1 and dist.get_backend(group) != "nccl" and local.tensors()[0].is_cuda
         self._host_local = None
-        for k in range(1, min(self.depth, last_step) + 1):
-            self.prefetch(k)
+        if self.depth >= last_step and last_step > 1:
+            # every step's shard fits: ONE batch (one RCCL group) carries all of them, so the transfers to the different
+            # peers run side by side, each over its own xGMI link.  Posted as one batch per step they would queue behind
+            # one another on the communicator's stream: step k's shard would arrive after k transfer times, not one.
+            self._post(list(range(1, last_step + 1)))
+        else:
+            for k in range(1, min(self.depth, last_step) + 1):
+                self.prefetch(k)
 
     def _peer(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -263,32 +269,43 @@ class _Ring:
     def prefetch(self, k):
         if k in self.pending or k <= 0 or k > self.last:
             return
-        src, dst = (self.rank + k) % self.world, (self.rank - k) % self.world
-        n_src = self.sizes[src]
-        slot = k % self.depth
-        if self.bufs[slot] is None and n_src:
-            self.bufs[slot] = self.ops.empty_packed(self.cap, self.local)
-        recv = self.bufs[slot].slice(0, n_src) if n_src else None
-        send_t = self.local.tensors() if self.local.n else []          # an empty shard is neither sent nor received
-        recv_t = recv.tensors() if n_src else []
-        host_recv = None
-        if self.stage:
-            if self._host_local is None:
-                self._host_local = [t.cpu() for t in send_t]
-            send_t = self._host_local
-            host_recv = [torch.empty(t.shape, dtype=t.dtype) for t in recv_t]
-        p2p = [dist.P2POp(dist.isend, t, self._peer(dst), self.group) for t in send_t]
-        p2p += [dist.P2POp(dist.irecv, t, self._peer(src), self.group) for t in (host_recv if self.stage else recv_t)]
+        self._post([k])
+
+    def _post(self, steps):
+        """Post the exchanges of `steps` as ONE batch of point-to-point operations."""
+        p2p, entries = [], []
+        for k in steps:
+            src, dst = (self.rank + k) % self.world, (self.rank - k) % self.world
+            n_src = self.sizes[src]
+            slot = k % self.depth
+            if self.bufs[slot] is None and n_src:
+                self.bufs[slot] = self.ops.empty_packed(self.cap, self.local)
+            recv = self.bufs[slot].slice(0, n_src) if n_src else None
+            send_t = self.local.tensors() if self.local.n else []          # an empty shard is neither sent nor received
+            recv_t = recv.tensors() if n_src else []
+            host_recv = None
+            if self.stage:
+                if self._host_local is None:
+                    self._host_local = [t.cpu() for t in send_t]
+                send_t = self._host_local
+                host_recv = [torch.empty(t.shape, dtype=t.dtype) for t in recv_t]
+            p2p += [dist.P2POp(dist.isend, t, self._peer(dst), self.group) for t in send_t]
+            p2p += [dist.P2POp(dist.irecv, t, self._peer(src), self.group) for t in (host_recv if self.stage else recv_t)]
+            entries.append((k, recv, host_recv))
         works = dist.batch_isend_irecv(p2p) if p2p else []
-        self.pending[k] = (works, recv, host_recv)
+        batch = {"works": works, "waited": False}        # waited once, whichever step asks first (a gloo recv must not be waited twice)
+        for k, recv, host_recv in entries:
+            self.pending[k] = (batch, recv, host_recv)
 
     def get(self, k):
         """The shard of rank + k (None when that shard is empty).  Also posts the transfer that may now reuse the
         buffer of step k - 1 (whose kernels are already queued on the stream)."""
         self.prefetch(k)
-        works, recv, host_recv = self.pending.pop(k)
-        for w in works:
-            w.wait()
+        batch, recv, host_recv = self.pending.pop(k)
+        if not batch["waited"]:
+            for w in batch["works"]:
+                w.wait()
+            batch["waited"] = True
         if host_recv is not None:
             for d, h in zip(recv.tensors() if recv is not None else [], host_recv):
                 d.copy_(h)
