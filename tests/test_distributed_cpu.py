@@ -123,6 +123,98 @@ class ToyOps:
         pass
 
 
+class ToyPrunedOps(ToyOps):
+    """ToyOps + a CPU stand-in for the pruned nearest-neighbour search of the supervised mode (pipeline.
+    alpha_weights_supervised): the "first pass" is exact here, but every `overflow_every`-th query row is declared
+    overflowed on every bank shard - on a subset of the ranks only when `ranks` is given - so that the ONE-flag decision,
+    its MAX all-reduce and the second trip of the bank shards round the ring all run under gloo."""
+    nn_prune = True
+
+    def __init__(self, overflow_every=0, ranks=None):
+        self.overflow_every, self.ranks = overflow_every, ranks
+
+    def h16(self, pk):
+        return pk.hl
+
+    def nn_slack(self, mk, mq):
+        return torch.zeros(3)
+
+    def nn_state(self, nq_rows, device):
+        class State:
+            pass
+        st = State()
+        st.n = nq_rows
+        st.best = torch.full((nq_rows,), float("inf"), dtype=torch.float64)
+        st.overflow = torch.zeros(1, dtype=torch.int32)
+        st.overflow_rows = torch.zeros(nq_rows, dtype=torch.int32)
+        return st
+
+    def _forced(self, n):
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        if not self.overflow_every or (self.ranks is not None and rank not in self.ranks):
+            return torch.zeros(n, dtype=torch.bool)
+        return (torch.arange(n) % self.overflow_every) == 0
+
+    def nn_scan(self, state, keys, keys_h16, queries, queries_h16, slack):
+        d2 = (torch.cdist(queries.hl, keys.hl) ** 2).min(1)[0].double()
+        over = self._forced(state.n)
+        state.best = torch.where(over, state.best, torch.minimum(state.best, d2))
+        if over.any():
+            state.overflow[0] = 1
+            state.overflow_rows[over] = 1
+
+    def nn_any_overflow(self, state):
+        return bool(int(state.overflow.item()))
+
+    def nn_overflow_queries(self, state, queries):
+        ops = self
+
+        class Over:
+            def __init__(self):
+                self.idx = state.overflow_rows.nonzero().flatten()
+                self.best = torch.full((self.idx.numel(),), float("inf"), dtype=torch.float64)
+
+            def scan(self, keys, budget=None):
+                if self.idx.numel() and keys is not None and keys.n:
+                    d2 = (torch.cdist(queries.hl[self.idx], keys.hl) ** 2).min(1)[0].double()
+                    self.best = torch.minimum(self.best, d2)
+
+            def commit(self, st):
+                st.best[self.idx] = self.best
+        return Over()
+
+    def nn_finalize(self, state, P):
+        return state.best.sqrt().float().reshape(-1, P)
+
+
+def _worker_pruned(rank, world, init_file, out_dir, overflow_every, ranks):
+    sys.path[:0] = [ROOT, MODELS]
+    from patchcore.pipeline import run_category
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    images, train = _inputs()
+    out = run_category(ToyPrunedOps(overflow_every, ranks), images, "supervised", tau=1.0, train_images=train, train_ratio=1.0)
+    np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overflow_every,ranks", [(3, 0, None), (3, 5, None), (4, 3, [2])])
+def test_supervised_pruned_search_collectives(world, overflow_every, ranks):
+    """The pruned search's distributed logic on a CPU stand-in: no overflow (one ring pass, one flag read), overflow on
+    every rank, and overflow on ONE rank only - the others must still join the second trip of the shards round the ring
+    (the flag is MAX all-reduced).  Every case equals the un-pruned one-rank result."""
+    from patchcore.pipeline import run_category
+    images, train = _inputs()
+    ref = run_category(ToyOps(), images, "supervised", tau=1.0, train_images=train, train_ratio=1.0)
+    one = run_category(ToyPrunedOps(overflow_every), images, "supervised", tau=1.0, train_images=train, train_ratio=1.0)
+    np.testing.assert_allclose(one["alpha"].numpy(), ref["alpha"].numpy(), rtol=1e-6)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_pruned, args=(world, os.path.join(d, "rdzv"), d, overflow_every, ranks), nprocs=world, join=True)
+        for r in range(world):
+            np.testing.assert_allclose(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].numpy(), rtol=1e-6)
+
+
 def _inputs(n=7, n_train=9):
     g = torch.Generator().manual_seed(11)
     return torch.randn(n, 3, 16, 16, generator=g), torch.randn(n_train, 3, 16, 16, generator=g)
