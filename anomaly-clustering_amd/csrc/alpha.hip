@@ -695,7 +695,7 @@ extern "C" int ac_nn_scatter_exhaustive(const uint32_t* acc_bits, const int32_t*
 // reference's un-shifted exp overflows.  tau == 0 (math.isclose(tau, 0) with its default
 // abs_tol = 0 is true only for exact zero): indicator of the maximum over #ties.
 __global__ __launch_bounds__(256) void alpha_softmax_kernel(const float* __restrict__ w, int P, double tau, double k,
-                                                            double* __restrict__ alpha) {
+                                                            double* __restrict__ alpha, float* __restrict__ alpha_f32) {
   __shared__ double red[4];
   __shared__ double bcast;
   const float* wi = w + (size_t)blockIdx.x * P;
@@ -724,15 +724,22 @@ __global__ __launch_bounds__(256) void alpha_softmax_kernel(const float* __restr
   if (tid == 0) bcast = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
   const double tot = bcast;
-  for (int p = tid; p < P; p += 256) ai[p] = ai[p] / tot;
+  // alpha_f32: examples/main.py:294's `.float()` of the same value (round to nearest even), for the weighted average
+  float* af = alpha_f32 ? alpha_f32 + (size_t)blockIdx.x * P : nullptr;
+  for (int p = tid; p < P; p += 256) {
+    const double a = ai[p] / tot;
+    ai[p] = a;
+    if (af) af[p] = (float)a;
+  }
 }
 
-extern "C" int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, void* stream) {
+extern "C" int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, float* alpha_f32,
+                                void* stream) {
   AC_REQUIRE(w && alpha, "ac_alpha_softmax: null pointer");
   AC_REQUIRE(P > 0 && N >= 0 && N <= 0x7fffffff, "ac_alpha_softmax: bad shape N=%lld P=%d", (long long)N, P);
   AC_REQUIRE(tau >= 0.0, "ac_alpha_softmax: tau=%g must be >= 0", tau);
   if (N == 0) return AC_OK;
-  hipLaunchKernelGGL(alpha_softmax_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), w, P, tau, k, alpha);
+  hipLaunchKernelGGL(alpha_softmax_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), w, P, tau, k, alpha, alpha_f32);
   return ac_check_launch("alpha_softmax");
 }
 

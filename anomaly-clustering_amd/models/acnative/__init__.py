@@ -68,7 +68,7 @@ SIGNATURES = {
     "ac_gather_rows": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "ac_nn_scatter_exhaustive": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "ac_nn_finalize": (_i, [_vp, _i64, _vp, _vp]),
-    "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
+    "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
     "ac_ward_workspace_bytes": (_sz, [_i64]),
@@ -411,9 +411,10 @@ def pack_images(Z):
     return Packed(hl, sq, n, P, D)
 
 
-def max_sq(packed_list, device):
-    """Running max of the squared norms over several packed blocks: fp32 [1] on the device."""
-    out = filled((1,), torch.float32, device, 0)
+def max_sq(packed_list, device, out=None):
+    """Running max of the squared norms over several packed blocks: fp32 [1] on the device (`out`: a 1-element view
+    of a vector the caller reduces across ranks in one collective)."""
+    out = filled((1,), torch.float32, device, 0) if out is None else fill_(out, 0)
     for pk in packed_list:
         if pk.n:
             _check(lib().ac_max_f32(pk.sq.data_ptr(), pk.sq.numel(), out.data_ptr(), _stream()))
@@ -594,14 +595,15 @@ class NNState:
     candidate list of the key set being scanned, and - sticky over the key sets - which queries had a list longer
     than their slots (overflow_rows) and whether any had (overflow: the ONE word the host reads, once per search)."""
 
-    def __init__(self, nq_rows, device, cap=NN_CAP):
+    def __init__(self, nq_rows, device, cap=NN_CAP, overflow=None):
         self.n, self.cap = nq_rows, cap
         self.approx_min = filled((nq_rows,), torch.int32, device, INF_BITS)
         self.best = filled((nq_rows,), torch.float64, device, F64_INF_BITS)
         self.cand = torch.empty((nq_rows, cap), dtype=torch.int32, device=device)
         self.count = filled((nq_rows,), torch.int32, device, 0)
         self.overflow_rows = filled((nq_rows,), torch.int32, device, 0)
-        self.overflow = filled((1,), torch.int32, device, 0)
+        # `overflow`: a 1-element int32 view of the caller's flag vector (several searches, ONE all-reduce, ONE read)
+        self.overflow = filled((1,), torch.int32, device, 0) if overflow is None else fill_(overflow, 0)
 
 
 def nn_scan(state, keys, keys_h16, queries, queries_h16, slack):
@@ -631,10 +633,16 @@ class OverflowQueries:
         dev = queries.hl.device
         P, D = queries.P, queries.D
         self.idx = torch.empty((max(state.n, 1),), dtype=torch.int32, device=dev)
+        self.n_rows = 0
+        self.packed = None
+        if state.n == 0:
+            # a rank without query images (fewer images than ranks) enters here whenever ANY rank overflowed (the flag is
+            # MAX all-reduced): it has nothing to re-measure - its zero-size tensors have no address to hand to the
+            # library - but still carries the bank shards round the second ring (scan / commit are no-ops)
+            return
         n_out = torch.empty(1, dtype=torch.int32, device=dev)
         _check(lib().ac_nn_overflow_compact(state.overflow_rows.data_ptr(), state.n, self.idx.data_ptr(), n_out.data_ptr(), _stream()))
         self.n_rows = int(n_out.item())                        # slow path: the host sizes the compact copy
-        self.packed = None
         if self.n_rows:
             rows = -(-self.n_rows // P) * P                    # the kernel's query axis comes in whole "images" of P rows
             hl = torch.empty((rows, D * 4), dtype=torch.uint8, device=dev)
@@ -671,14 +679,25 @@ def nn_finalize(state, P):
     return w
 
 
-def alpha_softmax(w, tau, k=1.0):
+def alpha_softmax(w, tau, k=1.0, want_f32=False):
+    """w fp32 [N, P] -> alpha fp64 [N, P] (utils.py:246-254); want_f32: also its fp32 rounding (main.py:294's
+    `.float()`), written by the same kernel -> (alpha, alpha_f32)."""
     p = _dev(w, torch.float32, "w")
     N, P = w.shape
     a = torch.empty((N, P), dtype=torch.float64, device=w.device)
-    if N == 0:
-        return a
-    _check(lib().ac_alpha_softmax(p, N, P, float(tau), float(k), a.data_ptr(), _stream()))
-    return a
+    a32 = torch.empty((N, P), dtype=torch.float32, device=w.device) if want_f32 else None
+    if N:
+        _check(lib().ac_alpha_softmax(p, N, P, float(tau), float(k), a.data_ptr(), a32.data_ptr() if want_f32 else None, _stream()))
+    return (a, a32) if want_f32 else a
+
+
+def alpha_average(n, P, device):
+    """The `average` weights (examples/main.py:290-291: ones / P) as fp32 [n, P]: the bit pattern of float32(1) /
+    float32(P) - what torch's `ones(...) / P` evaluates to - filled by the library."""
+    import struct
+    import numpy as np
+    bits = struct.unpack("<I", struct.pack("<f", float(np.float32(1.0) / np.float32(P))))[0]
+    return filled((n, P), torch.float32, device, bits)
 
 
 def weighted_avg(alpha, Z):

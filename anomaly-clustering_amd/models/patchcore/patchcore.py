@@ -91,6 +91,7 @@ class AnomalyClusteringCore(torch.nn.Module):
         self.anomaly_segmentor = patchcore.common.RescaleSegmentor(
             device=self.device, target_size=input_shape[-2:])
         self.featuresampler = featuresampler
+        self._zdims = None           # (P, D) of one image's Z, known after the first embedding
 
     # ------------------------------------------------------------------ embedding
     def embed(self, data, supervised):
@@ -118,12 +119,14 @@ class AnomalyClusteringCore(torch.nn.Module):
         on self.device.  This is what the MI355X pipeline (examples/main.py, bench.py) uses.  Z is allocated
         once and every batch's aggregation kernel writes its rows in place (no concatenation copy)."""
         N = images.shape[0]
-        Z = None
+        dims = getattr(self, "_zdims", None)
+        Z = torch.empty((N,) + dims, dtype=torch.float32, device=self.device) if (dims and N > batch_size) else None
         for s in range(0, N, batch_size):
             chunk = images[s:s + batch_size].to(self.device, dtype=torch.float32, non_blocking=True)
             if Z is None:
                 z = self._embed(chunk, None, detach=False)
                 rows = z.shape[0] // chunk.shape[0]
+                self._zdims = (rows, z.shape[-1])
                 if chunk.shape[0] == N:
                     return z.reshape(N, rows, z.shape[-1])
                 Z = torch.empty((N, rows, z.shape[-1]), dtype=torch.float32, device=self.device)
@@ -131,6 +134,57 @@ class AnomalyClusteringCore(torch.nn.Module):
             else:
                 self._embed(chunk, None, detach=False, out=Z[s:s + chunk.shape[0]])
         return Z
+
+    @torch.no_grad()
+    def embed_device_many(self, image_sets, batch_size=32):
+        """Several image sets -> [Z_i fp32 [n_i, P, D]] (views of ONE buffer), embedded as one stream of full
+        batches: a batch may span set boundaries (its images are then gathered into a staging buffer by
+        device-to-device copies; a batch inside one set is read in place).  The reference embeds one image per
+        forward (examples/main.py:213, batch_size=1); a rank of an 8-GPU run holds 5-21 images of an MVTec
+        category, and a ViT launch on 11 images runs at 78 % of the per-image rate of a launch on 128."""
+        counts = [int(s.shape[0]) for s in image_sets]
+        total = sum(counts)
+        if total == 0:
+            raise ValueError("embed_device_many: no images")
+        first = next(s for s in image_sets if s.shape[0])
+        shape = tuple(first.shape[1:])
+        stage = None
+        # the row shape of Z is known after the first embedding of this core: Z is then allocated up front and every
+        # batch writes in place (the very first call copies its first batch once)
+        dims = getattr(self, "_zdims", None)
+        Z_all = torch.empty((total,) + dims, dtype=torch.float32, device=self.device) if dims else None
+        # (set index, first, last) segments of the global image range
+        starts = [0]
+        for c in counts:
+            starts.append(starts[-1] + c)
+        for s in range(0, total, batch_size):
+            e = min(total, s + batch_size)
+            segs = [(i, max(s, starts[i]) - starts[i], min(e, starts[i + 1]) - starts[i])
+                    for i in range(len(counts)) if starts[i] < e and starts[i + 1] > s]
+            if len(segs) == 1:
+                i, a, b = segs[0]
+                chunk = image_sets[i][a:b].to(self.device, dtype=torch.float32, non_blocking=True)
+            else:
+                if stage is None:
+                    stage = torch.empty((batch_size,) + shape, dtype=torch.float32, device=self.device)
+                off = 0
+                for i, a, b in segs:
+                    stage[off: off + (b - a)].copy_(image_sets[i][a:b], non_blocking=True)
+                    off += b - a
+                chunk = stage[: e - s]
+            if Z_all is None:
+                z = self._embed(chunk, None, detach=False)
+                rows, D = z.shape[0] // chunk.shape[0], z.shape[-1]
+                self._zdims = (rows, D)
+                if e == total:
+                    Z_all = z.reshape(total, rows, D)
+                    break
+                Z_all = torch.empty((total, rows, D), dtype=torch.float32, device=self.device)
+                Z_all[: e - s].copy_(z.reshape(e - s, rows, D))
+                del z
+            else:
+                self._embed(chunk, None, detach=False, out=Z_all[s:e])
+        return [Z_all[starts[i]: starts[i + 1]] for i in range(len(counts))]
 
     def _embed(self, images, supervised, detach=True, provide_patch_shapes=False, out=None):
         """Reference :355-431.  `supervised` is accepted and ignored, as upstream.  out (extension): a

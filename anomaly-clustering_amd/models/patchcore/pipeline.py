@@ -48,6 +48,7 @@ only those are measured exactly (alpha_weights_supervised; csrc/alpha.hip).  No 
 world-size-2 gloo tests substitute a CPU stand-in to exercise the schedules and collectives.
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -129,6 +130,16 @@ class HipOps:
         self._zshape = tuple(Z.shape[1:])
         return Z
 
+    def embed_many(self, image_sets):
+        """Several image sets (the rank's shards of several categories) through the ViT as ONE stream of full
+        batches: [Z of set 0, Z of set 1, ...], views of one buffer.  A rank of an 8-GPU run holds 5-21 images of
+        an MVTec category - a fifth of a ViT batch; the sets of all 15 categories together fill whole batches."""
+        if sum(int(s.shape[0]) for s in image_sets) == 0:
+            return [self.embed(s) for s in image_sets]
+        Zs = self.core.embed_device_many(image_sets, batch_size=self.batch_size)
+        self._zshape = tuple(Zs[0].shape[1:])
+        return Zs
+
     # ---- packed blocks and the pair kernels (see acnative for the semantics)
     def pack(self, Z):
         return self.acnative.pack_images(Z)
@@ -136,8 +147,8 @@ class HipOps:
     def empty_packed(self, n, like):
         return self.acnative.Packed.empty(n, like.P, like.D, like.hl.device)
 
-    def max_sq(self, packed_list, device):
-        return self.acnative.max_sq(packed_list, device)
+    def max_sq(self, packed_list, device, out=None):
+        return self.acnative.max_sq(packed_list, device, out)
 
     def fixed_shift(self, max_sq_t, n_keys):
         return self.acnative.fixed_shift(max_sq_t, n_keys)
@@ -164,8 +175,8 @@ class HipOps:
     def nn_slack(self, max_sq_keys, max_sq_queries):
         return self.acnative.nn_slack(max_sq_keys, max_sq_queries)
 
-    def nn_state(self, nq_rows, device):
-        return self.acnative.NNState(nq_rows, device, self.nn_cap or self.acnative.NN_CAP)
+    def nn_state(self, nq_rows, device, overflow=None):
+        return self.acnative.NNState(nq_rows, device, self.nn_cap or self.acnative.NN_CAP, overflow)
 
     def nn_scan(self, state, keys, keys_h16, queries, queries_h16, slack):
         self.acnative.nn_scan(state, keys, keys_h16, queries, queries_h16, slack)        # nothing is read back
@@ -180,7 +191,12 @@ class HipOps:
         return self.acnative.nn_finalize(state, P)
 
     def alpha_softmax(self, w, tau, k):
-        return self.acnative.alpha_softmax(w, tau, k)
+        """-> (alpha fp64 [n, P], its fp32 copy: main.py:294's `.float()`), both written by the one kernel."""
+        return self.acnative.alpha_softmax(w, tau, k, want_f32=True)
+
+    def alpha_average(self, n, P, device):
+        """main.py:290-291: ones / P, as fp32 [n, P] (the bit pattern of float32(1/P), filled by the library)."""
+        return self.acnative.alpha_average(n, P, device)
 
     def weighted_avg(self, alpha_f32, Z):
         return self.acnative.weighted_avg(alpha_f32, Z)
@@ -202,10 +218,13 @@ def all_gather_rows(local, counts, group=None):
     """Concatenate per-rank row blocks of unequal length (counts[r] rows on rank r) on every rank.
     Pads to the largest block so one all_gather_into_tensor (one RCCL all-gather) moves everything.  With
     shard_bounds' layout (every non-empty shard but the last is full) the first sum(counts) rows of the
-    receive buffer ARE the concatenation - no second copy."""
-    rank, world = _world(group)
-    if world == 1:
+    receive buffer ARE the concatenation - no second copy.  len(counts) == 1: a run on one rank (or a rank
+    working a whole category on its own inside a larger job) - nothing to gather."""
+    if len(counts) == 1:
         return local
+    rank, world = _world(group)
+    if world != len(counts):
+        raise ValueError("all_gather_rows: %d counts for a group of %d ranks" % (len(counts), world))
     cap = max(counts)
     tail = local.shape[1:]
     send = local
@@ -242,7 +261,7 @@ class _Ring:
     Under a host backend (gloo: the CPU tests, and the tests that run several ranks on ONE GPU, which RCCL
     refuses) device tensors are staged through host memory."""
 
-    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES):
+    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES, post=True):
         self.ops, self.local, self.sizes, self.rank, self.world, self.group = ops, local, sizes, rank, world, group
         self.cap = max(sizes) if sizes else 0
         self.last = last_step
@@ -254,11 +273,30 @@ class _Ring:
         self.pending = {}
         self.stage = world > 1 and dist.get_backend(group) != "nccl" and local.tensors()[0].is_cuda
         self._host_local = None
-        if self.depth >= last_step and last_step > 1:
+        # depth is a function of the category's SHAPE and the caller's budget only, so every rank arrives at the same
+        # value and takes the same branch below; AC_RING_CHECK=1 proves it with an all-gather (diagnostic)
+        if world > 1 and os.environ.get("AC_RING_CHECK") == "1":
+            seen = [None] * world
+            dist.all_gather_object(seen, (self.depth, last_step), group=group)
+            if len(set(seen)) != 1:
+                raise RuntimeError("ring depth / last step differ across ranks: %r" % (seen,))
+        if post and last_step >= 1:
+            self.post()
+
+    def post(self):
+        """Post the first transfers: all of them as ONE batch when every step's shard has a buffer, else the first
+        `depth` steps.  AC_RING_POST=per_step keeps the older one-batch-per-step posting selectable (A/B on the first
+        multi-GPU node: transfers to different peers then queue behind one another on the communicator's stream)."""
+        last_step = self.last
+        if self.depth >= last_step and last_step > 1 and os.environ.get("AC_RING_POST", "batch") != "per_step":
             # every step's shard fits: ONE batch (one RCCL group) carries all of them, so the transfers to the different
             # peers run side by side, each over its own xGMI link.  Posted as one batch per step they would queue behind
             # one another on the communicator's stream: step k's shard would arrive after k transfer times, not one.
-            self._post(list(range(1, last_step + 1)))
+            steps = list(range(1, last_step + 1))
+            slots = [k % self.depth for k in steps]
+            if len(set(slots)) != len(slots):
+                raise RuntimeError("ring: batched steps %r share receive buffers %r" % (steps, slots))
+            self._post(steps)
         else:
             for k in range(1, min(self.depth, last_step) + 1):
                 self.prefetch(k)
@@ -317,6 +355,73 @@ def _slice_global(pk, base, rng):
     return pk.slice(rng[0] - base, rng[1] - base)
 
 
+class _UnsupJob:
+    """The unsupervised weights of ONE category on one rank (utils.py:222-227 for every image of the shard), cut into
+    the phases that run_category walks in order and run_categories interleaves across categories:
+
+        __init__   squared-norm maximum of the local shard   -> self.m (fp32 [1]; MAX all-reduce it across ranks)
+        prepare    fixed-point scale from m, int64 sums      -> self.acc ([N*P]; SUM all-reduce it after the last step)
+        post       the ring: every step's shard transfer posted (one batch)
+        run(step)  the block launches of one ring step; step 0 needs no remote data
+        finish     w fp32 [n_loc, P]
+
+    `m` and `acc` may be views of tensors the caller owns (run_categories keeps ONE vector of maxima and ONE
+    accumulator for all categories, so that each costs one collective instead of one per category)."""
+
+    def __init__(self, ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
+                 m_out=None, acc=None):
+        self.ops, self.pk, self.bounds, self.rank, self.world, self.group, self.device = ops, pk_loc, bounds, rank, world, group, device
+        self.n = bounds[-1][1]
+        self.lo, self.hi = bounds[rank]
+        self.P = pk_loc.P
+        self.counts = [b - a for a, b in bounds]
+        self.budget, self.remote_bytes = budget, remote_bytes
+        self.m = ops.max_sq([pk_loc], device) if m_out is None else ops.max_sq([pk_loc], device, out=m_out)
+        self.acc = acc
+        self.ring = None
+        self.last_step = world // 2
+
+    def prepare(self):
+        ops, P = self.ops, self.P
+        self.shift = ops.fixed_shift(self.m, self.n)
+        if self.acc is None:
+            self.acc = ops.new_acc(self.n * P, MEAN, self.device)          # sums for EVERY image: remote queries' parts too
+        self.by_step = {}
+        for item in unsup_schedule(self.bounds, self.rank, block_images(P, self.budget)):
+            self.by_step.setdefault(item[1], []).append(item)
+
+    def post(self):
+        self.ring = _Ring(self.ops, self.pk, self.counts, self.rank, self.world, self.group, last_step=self.last_step,
+                          remote_bytes=self.remote_bytes)
+
+    def run(self, step):
+        ops, P, acc, shift, lo = self.ops, self.P, self.acc, self.shift, self.lo
+        remote, rbase = None, 0
+        if step > 0:                                       # every rank takes part in every exchange, work or not
+            remote = self.ring.get(step)
+            rbase = self.bounds[(self.rank + step) % self.world][0]
+        for item in self.by_step.get(step, []):
+            if item[0] == "sym":
+                a = item[2]
+                A = _slice_global(self.pk, lo, a)
+                mb = ops.pair_block(A, A)
+                ops.pair_accumulate(mb, P, MEAN, 0, shift, acc[a[0] * P: a[1] * P])
+            else:
+                a, b = item[2], item[3]
+                A = _slice_global(self.pk, lo, a)
+                B = _slice_global(self.pk, lo, b) if step == 0 else _slice_global(remote, rbase, b)
+                if a[0] > b[0]:        # canonical orientation: the block with the LOWER image indices is the row
+                    a, b, A, B = b, a, B, A   # operand, whichever rank computes it (a.b and b.a differ in the last bit)
+                mb, mbt = ops.pair_block(A, B, two_way=True)
+                ops.pair_accumulate(mb, P, MEAN, NO_SELF, shift, acc[b[0] * P: b[1] * P])     # keys A, queries B
+                ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[a[0] * P: a[1] * P])    # keys B, queries A
+
+    def finish(self):
+        P = self.P
+        self.ring = None
+        return self.ops.pair_finalize(self.acc[self.lo * P: self.hi * P], P, MEAN, self.n - 1, self.shift)
+
+
 def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto",
                                remote_bytes=REMOTE_BYTES):
     """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard)."""
@@ -340,39 +445,76 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
         ops.pair_accumulate(minbuf[:, lo * P: hi * P], P, MEAN, lo, shift, acc)
         return ops.pair_finalize(acc, P, MEAN, n - 1, shift)
 
-    m = ops.max_sq([pk_loc], device)
+    job = _UnsupJob(ops, pk_loc, bounds, rank, world, group, device, budget, remote_bytes)
     if world > 1:
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-    shift = ops.fixed_shift(m, n)
-    acc = ops.new_acc(n * P, MEAN, device)                 # sums for EVERY image: remote queries' parts too
-    c = block_images(P, budget)
-    ring = _Ring(ops, pk_loc, counts, rank, world, group, last_step=world // 2, remote_bytes=remote_bytes)
-    by_step = {}
-    for item in unsup_schedule(bounds, rank, c):
-        by_step.setdefault(item[1], []).append(item)
-    for step in range(0, world // 2 + 1):
-        remote, rbase = None, 0
-        if step > 0:                                       # every rank takes part in every exchange, work or not
-            remote = ring.get(step)
-            rbase = bounds[(rank + step) % world][0]
-        for item in by_step.get(step, []):
-            if item[0] == "sym":
-                a = item[2]
-                A = _slice_global(pk_loc, lo, a)
-                mb = ops.pair_block(A, A)
-                ops.pair_accumulate(mb, P, MEAN, 0, shift, acc[a[0] * P: a[1] * P])
-            else:
-                a, b = item[2], item[3]
-                A = _slice_global(pk_loc, lo, a)
-                B = _slice_global(pk_loc, lo, b) if step == 0 else _slice_global(remote, rbase, b)
-                if a[0] > b[0]:        # canonical orientation: the block with the LOWER image indices is the row
-                    a, b, A, B = b, a, B, A   # operand, whichever rank computes it (a.b and b.a differ in the last bit)
-                mb, mbt = ops.pair_block(A, B, two_way=True)
-                ops.pair_accumulate(mb, P, MEAN, NO_SELF, shift, acc[b[0] * P: b[1] * P])     # keys A, queries B
-                ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[a[0] * P: a[1] * P])    # keys B, queries A
+        dist.all_reduce(job.m, op=dist.ReduceOp.MAX, group=group)
+    job.prepare()
+    job.post()
+    for step in range(0, job.last_step + 1):
+        job.run(step)
     if world > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-    return ops.pair_finalize(acc[lo * P: hi * P], P, MEAN, n - 1, shift)
+        dist.all_reduce(job.acc, op=dist.ReduceOp.SUM, group=group)
+    return job.finish()
+
+
+class _SupJob:
+    """The supervised weights of ONE category on one rank as a pruned EXACT nearest-neighbour search, in phases (see
+    _UnsupJob): __init__ (maxima mk, mq: MAX all-reduce both) -> prepare -> post (the bank shards' ring) -> run(k) for
+    k = 0 .. world-1 (k = 0: the rank's own bank shard) -> the overflow flag `state.overflow` (MAX all-reduce, ONE
+    host read) -> fix() when it is set (collective: every rank or none) -> finish."""
+
+    def __init__(self, ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
+                 remote_bytes=REMOTE_BYTES, m_out=None, overflow=None):
+        self.ops, self.pk, self.bank, self.rank, self.world, self.group, self.device = ops, pk_loc, pk_bank_loc, rank, world, group, device
+        self.P, self.n_loc = pk_loc.P, pk_loc.n
+        self.counts = [b - a for a, b in bank_bounds]
+        self.budget, self.remote_bytes = budget, remote_bytes
+        if m_out is None:
+            self.mk, self.mq = ops.max_sq([pk_bank_loc], device), ops.max_sq([pk_loc], device)
+        else:                                       # views of the caller's vector: one MAX all-reduce for all categories
+            self.mk, self.mq = ops.max_sq([pk_bank_loc], device, out=m_out[0:1]), ops.max_sq([pk_loc], device, out=m_out[1:2])
+        self._overflow = overflow
+        self.last_step = world - 1
+        self.ring = None
+
+    def prepare(self):
+        ops = self.ops
+        self.slack = ops.nn_slack(self.mk, self.mq)          # the bound must hold for every (query, bank patch) pair of the run
+        self.state = (ops.nn_state(self.n_loc * self.P, self.device) if self._overflow is None
+                      else ops.nn_state(self.n_loc * self.P, self.device, overflow=self._overflow))
+        self.q16 = ops.h16(self.pk)
+
+    def _new_ring(self):
+        return _Ring(self.ops, self.bank, self.counts, self.rank, self.world, self.group, last_step=self.last_step,
+                     remote_bytes=self.remote_bytes)
+
+    def post(self):
+        self.ring = self._new_ring()
+
+    def run(self, k):
+        keys = self.bank if k == 0 else self.ring.get(k)
+        if keys is None or keys.n == 0 or self.n_loc == 0:
+            return
+        self.ops.nn_scan(self.state, keys, self.ops.h16(keys), self.pk, self.q16, self.slack)
+
+    def fix(self):
+        """Some query patch, on some rank, had more near-ties than candidate slots (e.g. a uniform background against a
+        bank of the same background): the marked queries of EVERY rank meet the whole bank again through the exhaustive
+        one-way split-fp16 blocks, on a compact copy, and take that answer as it stands (bit-equal to prune=False).  A
+        rank without marked queries (or without images) still carries the shards round the ring."""
+        over = self.ops.nn_overflow_queries(self.state, self.pk)
+        ring = self._new_ring()
+        for k in range(self.world):
+            over.scan(self.bank if k == 0 else ring.get(k), self.budget)
+        over.commit(self.state)
+
+    def finish(self):
+        self.ring = None
+        return self.ops.nn_finalize(self.state, self.P)
+
+
+def _can_prune(ops, pk_loc, prune):
+    return bool(prune and getattr(ops, "nn_prune", False) and pk_loc.D % 64 == 0)
 
 
 def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
@@ -388,35 +530,25 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     n_loc = pk_loc.n
     counts = [b - a for a, b in bank_bounds]
     m = sum(counts)
-    if prune and getattr(ops, "nn_prune", False) and pk_loc.D % 64 == 0:
-        mk, mq = ops.max_sq([pk_bank_loc], device), ops.max_sq([pk_loc], device)
-        if world > 1:                               # the bound must hold for every (query, bank patch) pair of the run
-            dist.all_reduce(mk, op=dist.ReduceOp.MAX, group=group)
-            dist.all_reduce(mq, op=dist.ReduceOp.MAX, group=group)
-        slack = ops.nn_slack(mk, mq)
-        state = ops.nn_state(n_loc * P, device)
-        q16 = ops.h16(pk_loc)
-        ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
-        for k in range(world):                      # the whole ring is queued without a host read
-            keys = pk_bank_loc if k == 0 else ring.get(k)
-            if keys is None or keys.n == 0 or n_loc == 0:
-                continue
-            ops.nn_scan(state, keys, ops.h16(keys), pk_loc, q16, slack)
-        # ONE host read per search: did any query patch, on any bank shard, have more near-ties than candidate slots
-        # (e.g. a uniform background against a bank of the same background)?  On ordinary data: no, and this is
-        # all.  Otherwise those queries - on every rank, hence the MAX all-reduce of the flag: the ring is collective
-        # - meet the whole bank again through the exhaustive one-way split-fp16 blocks, on a compact copy, and take
-        # that answer as it stands (bit-equal to prune=False).  A bank on which every query overflows therefore costs
-        # one wasted first pass (a third of the exhaustive work) - the bound of the regression against prune=False.
+    if _can_prune(ops, pk_loc, prune):
+        job = _SupJob(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget, remote_bytes)
         if world > 1:
-            dist.all_reduce(state.overflow, op=dist.ReduceOp.MAX, group=group)
-        if ops.nn_any_overflow(state):
-            over = ops.nn_overflow_queries(state, pk_loc)
-            ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
-            for k in range(world):
-                over.scan(pk_bank_loc if k == 0 else ring.get(k), budget)
-            over.commit(state)
-        return ops.nn_finalize(state, P)
+            dist.all_reduce(job.mk, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(job.mq, op=dist.ReduceOp.MAX, group=group)
+        job.prepare()
+        job.post()
+        for k in range(world):                      # the whole ring is queued without a host read
+            job.run(k)
+        # ONE host read per search: did any query patch, on any bank shard, have more near-ties than candidate slots?
+        # On ordinary data: no, and this is all.  Otherwise those queries - on every rank, hence the MAX all-reduce of
+        # the flag: the ring is collective - take the exhaustive path (fix).  A bank on which every query overflows
+        # therefore costs one wasted first pass (a third of the exhaustive work) - the bound of the regression against
+        # prune=False.
+        if world > 1:
+            dist.all_reduce(job.state.overflow, op=dist.ReduceOp.MAX, group=group)
+        if ops.nn_any_overflow(job.state):
+            job.fix()
+        return job.finish()
     acc = ops.new_acc(n_loc * P, MIN, device)
     ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
     c = block_images(P, budget)
@@ -432,9 +564,55 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     return ops.pair_finalize(acc, P, MIN, m, None)
 
 
+def _alpha_pair(ops, w_loc, Z_loc, tau, k):
+    """(alpha fp64-or-None, alpha fp32 [n_loc, P]) for one tau; w_loc None: the `average` weights (main.py:290-291)."""
+    if w_loc is None:
+        if hasattr(ops, "alpha_average"):
+            return None, ops.alpha_average(Z_loc.shape[0], Z_loc.shape[1], Z_loc.device)
+        return None, torch.ones(Z_loc.shape[0], Z_loc.shape[1], device=Z_loc.device) / Z_loc.shape[1]
+    res = ops.alpha_softmax(w_loc, tau, k)
+    if isinstance(res, tuple):                                             # the kernel wrote main.py:294's `.float()` too
+        return res
+    return res, res.float().contiguous()
+
+
+def _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host, mark):
+    """alpha = softmax(w / tau), X = alpha . Z, the all-gathers north_star names, pdist on rank 0 - per tau.
+    w does not depend on tau (and Z not on the mode): a tau sweep - the reference re-runs everything per tau
+    (examples/main.py:346-366, README "tau_list") - only repeats this cheap tail."""
+    taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
+    by_tau = {}
+    for tv in taus:
+        t0 = time.perf_counter()
+        _, alpha_f32 = _alpha_pair(ops, w_loc, Z_loc, tv, k)
+        X_loc = ops.weighted_avg(alpha_f32, Z_loc)
+        X = all_gather_rows(X_loc, counts, group)
+        alpha = all_gather_rows(alpha_f32, counts, group).unsqueeze(1)
+        mark("alpha_softmax_weighted_avg_gather", t0)
+        res = {"alpha": alpha, "X_dev": X}
+        t0 = time.perf_counter()
+        if want_pdist and rank == 0:
+            res["pdist"] = ops.pdist(X)
+        mark("pdist", t0)
+        if want_host:
+            res["X"] = np.array(X.cpu().numpy(), dtype=np.float32, copy=True)  # main.py:294-296 `.cpu()` + np.array
+        by_tau[float(tv)] = res
+    out = dict(by_tau[float(taus[0])])
+    out["by_tau"] = by_tau
+    return out
+
+
+def _marker(ops, timings):
+    def mark(name, t0):
+        if timings is not None:
+            ops.sync()
+            timings[name] = timings.get(name, 0.0) + (time.perf_counter() - t0)
+    return mark
+
+
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
-                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True):
+                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True, solo=False):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
@@ -444,18 +622,14 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     Z_loc: the rank's embeddings from an earlier call on the same images (out["Z_loc"]): Z does not depend on
     the mode, so a run over several modes embeds the test set once (the reference re-embeds per mode and per tau,
     examples/main.py:346-366).
+    solo: work the whole category on THIS rank although a process group exists (no collective at all).
     Returns dict(alpha fp32 [N, 1, P] on device, X float32 ndarray [N, D], X_dev, pdist (rank 0), bounds)."""
-    rank, world = _world(group)
+    rank, world = (0, 1) if solo else _world(group)
     n = images.shape[0]
     bounds = shard_bounds(n, world)
     lo, hi = bounds[rank]
     counts = [b - a for a, b in bounds]
-    t = {} if timings is None else timings
-
-    def mark(name, t0):
-        if timings is not None:
-            ops.sync()
-            t[name] = t.get(name, 0.0) + (time.perf_counter() - t0)
+    mark = _marker(ops, timings)
 
     t0 = time.perf_counter()
     if Z_loc is None:
@@ -483,32 +657,278 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         w_loc = None
     mark("pair_min_dist", t0)
 
-    # w does not depend on tau (and Z not on the mode): a tau sweep - the reference re-runs everything per
-    # tau (examples/main.py:346-366, README "tau_list") - only repeats the cheap tail below.
-    taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
-    by_tau = {}
-    for tv in taus:
-        t0 = time.perf_counter()
-        if w_loc is None:
-            alpha_loc = torch.ones(Z_loc.shape[0], Z_loc.shape[1], device=Z_loc.device) / Z_loc.shape[1]
-        else:
-            alpha_loc = ops.alpha_softmax(w_loc, tv, k)
-        alpha_f32 = alpha_loc.float().contiguous()                     # main.py:294 `.float()`
-        X_loc = ops.weighted_avg(alpha_f32, Z_loc)
-        X = all_gather_rows(X_loc, counts, group)
-        alpha = all_gather_rows(alpha_f32, counts, group).unsqueeze(1)
-        mark("alpha_softmax_weighted_avg_gather", t0)
-        res = {"alpha": alpha, "X_dev": X}
-        t0 = time.perf_counter()
-        if want_pdist and rank == 0:
-            res["pdist"] = ops.pdist(X)
-        mark("pdist", t0)
-        if want_host:
-            res["X"] = np.array(X.cpu().numpy(), dtype=np.float32, copy=True)  # main.py:294-296 `.cpu()` + np.array
-        by_tau[float(tv)] = res
-    out = dict(by_tau[float(taus[0])])
+    out = _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host, mark)
     out["bounds"] = bounds
-    out["by_tau"] = by_tau
     out["w_loc"] = w_loc
     out["Z_loc"] = Z_loc
     return out
+
+
+# ------------------------------------------------------------------ several categories as one job
+GROUP_IMAGES = 2048           # images (test + bank) one rank embeds and packs before their alpha work starts: 2 x 26 GB
+RING_BYTES_ALL = 48 << 30     # receive buffers of ALL rings that are in flight at once
+
+
+def lpt_assignment(costs, world):
+    """Longest-processing-time-first: item indices per rank, heaviest first onto the least loaded rank (ties: the
+    lower rank).  Deterministic, so every rank computes the same table.  -> (list of index lists, loads)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads, mine = [0.0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda q: (loads[q], q))
+        mine[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(m) for m in mine], loads
+
+
+def category_cost(n, m=None, t_img=0.46e-3, t_pair=6.2e-6):
+    """Seconds one MI355X spends on a category of n test images (m bank images: supervised): n ViT forwards + the
+    ordered alpha pairs.  Defaults: measured on MI355X (DESIGN.md section 4: 0.46 ms per image at batch 128;
+    42.2 ms for the 83 * 82 ordered pairs of config 2; a pruned bank pair costs 0.36 of an exhaustive unsupervised one)."""
+    if m is None:
+        return n * t_img + n * (n - 1) * t_pair
+    return (n + m) * t_img + n * m * t_pair * 0.72
+
+
+def _embed_sets(ops, sets):
+    if hasattr(ops, "embed_many"):
+        return ops.embed_many(sets)
+    return [ops.embed(s) for s in sets]
+
+
+def _groups(sizes, limit):
+    """Consecutive runs of categories whose per-rank image counts stay within `limit` (a single larger one alone)."""
+    out, cur, tot = [], [], 0
+    for i, sz in enumerate(sizes):
+        if cur and tot + sz > limit:
+            out.append(cur)
+            cur, tot = [], 0
+        cur.append(i)
+        tot += sz
+    if cur:
+        out.append(cur)
+    return out
+
+
+def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ratio=1.0, group=None, bank_seed=0,
+                   want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
+                   prune=True, schedule="pipeline", group_images=GROUP_IMAGES, ring_bytes_all=RING_BYTES_ALL,
+                   costs=None, solo=False):
+    """Several categories as ONE job.  items: [{"images": [N_c, 3, H, W], "train_images": bank candidates or None}].
+    Returns [run_category's dict per category]; the numbers are those of the per-category loop the reference runs
+    (examples/main.py:346-366) - bit for bit given the same embeddings - only the ORDER of the work changes:
+
+      "pipeline" (default)  every category sharded over all ranks, as run_category does, but
+           1. the rank's shards of ALL categories (and of their banks) go through the ViT as one stream of FULL batches
+              (8 ranks: 5-21 images per category and rank, 216 over the 15 MVTec categories);
+           2. every category is packed and the transfers of ALL rings are posted, category by category, before any
+              alpha work: the shards of category c + 1 travel while the blocks of category c are multiplied;
+           3. the ring step that needs no remote data (the rank's own shard: symmetric block / own bank shard) runs for
+              ALL categories first - tens of ms of MFMA work for the first transfers to hide under - then the remaining
+              steps, category by category;
+           4. the fixed-point scales of all categories come from ONE MAX all-reduce (a vector), their int64 sums from
+              ONE SUM all-reduce (one buffer), the supervised overflow flags from ONE MAX all-reduce and ONE host read.
+      "sequential"   run_category per category, one after another (the reference's loop; the round-3 behaviour).
+      "per_gpu"      whole categories to ranks by longest-processing-time-first on category_cost (or `costs`); every
+           rank works its categories alone (no ring, no all-reduce) and ONE all-gather hands X / alpha of every category
+           to every rank.  Bound: sum(cost) / max over ranks - 15 MVTec categories on 8 GPUs: 6.4x; SURVEY 8e lists it
+           as the alternative to the image-sharded schedule north_star specifies.
+
+    Categories are taken in groups of at most `group_images` images per rank (Z + packed copy: 25.7 MB per image).
+    solo: this rank works ALL of `items` alone although a process group exists (how "per_gpu" runs a rank's share)."""
+    rank, world = (0, 1) if solo else _world(group)
+    mark = _marker(ops, timings)
+    ncat = len(items)
+    if ncat == 0:
+        return []
+    if supervised == "supervised" and any(it.get("train_images") is None for it in items):
+        raise ValueError("supervised alpha needs train_images for every category")
+
+    def one(it):
+        return run_category(ops, it["images"], supervised, tau=tau, k=k, train_images=it.get("train_images"),
+                            train_ratio=train_ratio, group=group, bank_seed=bank_seed, want_pdist=want_pdist,
+                            want_host=want_host, timings=timings, budget=budget, remote_bytes=remote_bytes, prune=prune,
+                            solo=solo)
+
+    if schedule == "sequential":
+        return [one(it) for it in items]
+    if schedule == "per_gpu":
+        return _run_categories_per_gpu(ops, items, supervised, tau, k, train_ratio, group, bank_seed, want_pdist,
+                                       want_host, timings, budget, prune, costs, group_images)
+    if schedule != "pipeline":
+        raise ValueError("unknown category schedule %r" % (schedule,))
+
+    ns = [int(it["images"].shape[0]) for it in items]
+    all_bounds = [shard_bounds(n, world) for n in ns]
+    sels, bank_bounds = [None] * ncat, [None] * ncat
+    if supervised == "supervised":
+        for c, it in enumerate(items):
+            sels[c] = select_bank(it["train_images"].shape[0], ns[c], train_ratio, bank_seed)
+            bank_bounds[c] = shard_bounds(len(sels[c]), world)
+    # per-rank load of a category: the LARGEST shard (every rank must cut the same groups)
+    per_rank = [max(b - a for a, b in all_bounds[c]) + (max(b - a for a, b in bank_bounds[c]) if bank_bounds[c] else 0)
+                for c in range(ncat)]
+    outs = [None] * ncat
+    for grp in _groups(per_rank, group_images):
+        # ---- 1. one stream of ViT batches for the group
+        t0 = time.perf_counter()
+        sets = [items[c]["images"][all_bounds[c][rank][0]: all_bounds[c][rank][1]] for c in grp]
+        if supervised == "supervised":
+            for c in grp:
+                blo, bhi = bank_bounds[c][rank]
+                sets.append(items[c]["train_images"][sels[c][blo:bhi]])
+        Zs = _embed_sets(ops, sets)
+        Z = {c: Zs[i] for i, c in enumerate(grp)}
+        Zb = {c: Zs[len(grp) + i] for i, c in enumerate(grp)} if supervised == "supervised" else {}
+        del Zs
+        mark("embed", t0)
+        device = Z[grp[0]].device
+
+        # ---- 2.-4. the alpha weights of the group
+        t0 = time.perf_counter()
+        w = {c: None for c in grp}
+        if supervised in ("unsupervised", "supervised"):
+            pk = {c: ops.pack(Z[c]) for c in grp}
+            P = pk[grp[0]].P
+            sup = supervised == "supervised"
+            if sup:
+                pkb = {c: ops.pack(Zb[c]) for c in grp}
+                Zb.clear()
+            if sup and not _can_prune(ops, pk[grp[0]], prune):
+                for c in grp:          # exhaustive blocks: no phases to interleave
+                    w[c] = alpha_weights_supervised(ops, pk[c], pkb[c], bank_bounds[c], rank, world, group, device, budget,
+                                                    remote_bytes, prune)
+            else:
+                # the rings of the group must ALL be fully posted (depth = every step); a group whose receive buffers
+                # exceed the budget falls back to the category-by-category order (each ring double-buffers on its own)
+                steps = (world - 1) if sup else world // 2
+                ring_total = sum(steps * (pk[c].D * 4 + 4) * P * max((b - a) for a, b in (bank_bounds[c] if sup else all_bounds[c]))
+                                 for c in grp)
+                together = world > 1 and ring_total <= ring_bytes_all and all(
+                    steps * (pk[c].D * 4 + 4) * P * max((b - a) for a, b in (bank_bounds[c] if sup else all_bounds[c])) <= remote_bytes
+                    for c in grp)
+                m_all = ops.new_acc(len(grp), MEAN, device).view(torch.float32)       # 2 fp32 maxima per category, zeros
+                jobs = {}
+                if sup:
+                    flags = ops.new_acc(len(grp), MEAN, device)                          # int64 zeros; int32 view below
+                    flags32 = flags.view(torch.int32)[: len(grp)]
+                    for i, c in enumerate(grp):
+                        jobs[c] = _SupJob(ops, pk[c], pkb[c], bank_bounds[c], rank, world, group, device, budget, remote_bytes,
+                                          m_out=m_all[2 * i: 2 * i + 2], overflow=flags32[i: i + 1])
+                else:
+                    acc_all = ops.new_acc(sum(ns[c] for c in grp) * P, MEAN, device)
+                    off = 0
+                    for i, c in enumerate(grp):
+                        jobs[c] = _UnsupJob(ops, pk[c], all_bounds[c], rank, world, group, device, budget, remote_bytes,
+                                            m_out=m_all[2 * i: 2 * i + 1], acc=acc_all[off * P: (off + ns[c]) * P])
+                        off += ns[c]
+                if world > 1:
+                    dist.all_reduce(m_all, op=dist.ReduceOp.MAX, group=group)
+                for c in grp:
+                    jobs[c].prepare()
+                if together or world == 1:
+                    for c in grp:
+                        jobs[c].post()
+                    for c in grp:                      # no remote data needed: the first transfers hide under ALL of these
+                        jobs[c].run(0)
+                    for c in grp:
+                        for step in range(1, jobs[c].last_step + 1):
+                            jobs[c].run(step)
+                else:
+                    for c in grp:
+                        jobs[c].post()
+                        for step in range(0, jobs[c].last_step + 1):
+                            jobs[c].run(step)
+                        jobs[c].ring = None
+                if sup:
+                    if world > 1:
+                        dist.all_reduce(flags32, op=dist.ReduceOp.MAX, group=group)
+                    over = [bool(v) for v in flags32.cpu().tolist()]                     # ONE host read for the group
+                    for i, c in enumerate(grp):
+                        if over[i]:
+                            jobs[c].fix()
+                elif world > 1:
+                    dist.all_reduce(acc_all, op=dist.ReduceOp.SUM, group=group)
+                for c in grp:
+                    w[c] = jobs[c].finish()
+                del jobs
+            del pk
+        mark("pair_min_dist", t0)
+
+        # ---- the cheap tail, per category
+        for c in grp:
+            counts = [b - a for a, b in all_bounds[c]]
+            out = _tail(ops, w[c], Z[c], counts, group, rank, tau, k, want_pdist, want_host, mark)
+            out["bounds"] = all_bounds[c]
+            out["w_loc"] = w[c]
+            out["Z_loc"] = Z[c]
+            outs[c] = out
+        del Z
+    return outs
+
+
+def _run_categories_per_gpu(ops, items, supervised, tau, k, train_ratio, group, bank_seed, want_pdist, want_host, timings,
+                            budget, prune, costs, group_images):
+    """Whole categories to ranks (see run_categories): every rank runs ITS categories as a one-rank pipeline job, then ONE
+    all-gather of rows (X | alpha) per tau puts every category's result on every rank; rank 0 computes the distances."""
+    rank, world = _world(group)
+    mark = _marker(ops, timings)
+    ns = [int(it["images"].shape[0]) for it in items]
+    if costs is None:
+        costs = [category_cost(n, min(int(it["train_images"].shape[0]), int(train_ratio * n)) if supervised == "supervised" else None)
+                 for n, it in zip(ns, items)]
+    table, _ = lpt_assignment(list(costs), world)
+    mine = table[rank]
+    local = run_categories(ops, [items[c] for c in mine], supervised, tau=tau, k=k, train_ratio=train_ratio, group=group,
+                           bank_seed=bank_seed, want_pdist=False, want_host=False, timings=timings, budget=budget,
+                           prune=prune, schedule="pipeline", group_images=group_images, solo=True) if mine else []
+    taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
+    outs = [dict(bounds=shard_bounds(n, 1), w_loc=None, Z_loc=None, by_tau={}) for n in ns]
+    for r, cats in enumerate(table):
+        for c in cats:
+            outs[c]["owner"] = r
+    for c, res in zip(mine, local):
+        outs[c]["w_loc"], outs[c]["Z_loc"] = res["w_loc"], res["Z_loc"]
+    dims = (int(local[0]["X_dev"].shape[1]), int(local[0]["alpha"].shape[2])) if local else None
+    if world > 1 and any(not cats for cats in table):          # more ranks than categories: an idle rank asks for the row width
+        seen = [None] * world
+        dist.all_gather_object(seen, dims, group=group)
+        dims = next(v for v in seen if v is not None)
+    rows = [sum(ns[c] for c in cats) for cats in table]
+    device = local[0]["X_dev"].device if local else getattr(items[0]["images"], "device", None)
+    for tv in taus:
+        t0 = time.perf_counter()
+        full = None
+        if world > 1:
+            D, P = dims
+            send = torch.empty((rows[rank], D + P), dtype=torch.float32, device=device)
+            off = 0
+            for c, res in zip(mine, local):
+                r_tv = res["by_tau"][float(tv)]
+                send[off: off + ns[c], :D].copy_(r_tv["X_dev"])
+                send[off: off + ns[c], D:].copy_(r_tv["alpha"].squeeze(1))
+                off += ns[c]
+            full = all_gather_rows(send, rows, group)
+        off = 0
+        for r, cats in enumerate(table):
+            for c in cats:
+                if full is not None:
+                    blk = full[off: off + ns[c]]
+                    off += ns[c]
+                    res = {"X_dev": blk[:, :dims[0]].contiguous(), "alpha": blk[:, dims[0]:].contiguous().unsqueeze(1)}
+                else:
+                    src = local[mine.index(c)]["by_tau"][float(tv)]
+                    res = {"X_dev": src["X_dev"], "alpha": src["alpha"]}
+                outs[c]["by_tau"][float(tv)] = res
+        mark("alpha_softmax_weighted_avg_gather", t0)
+        t0 = time.perf_counter()
+        for c in range(len(items)):
+            res = outs[c]["by_tau"][float(tv)]
+            if want_pdist and rank == 0:
+                res["pdist"] = ops.pdist(res["X_dev"])
+            if want_host:
+                res["X"] = np.array(res["X_dev"].cpu().numpy(), dtype=np.float32, copy=True)
+        mark("pdist", t0)
+    for c in range(len(items)):
+        outs[c].update(outs[c]["by_tau"][float(taus[0])])
+    return outs

@@ -270,8 +270,9 @@ int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream);
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
  *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;
  *   else alpha = k*exp(w/tau) / sum, computed max-shifted (same value, no overflow).
- * w fp32 [N, P] -> alpha fp64 [N, P]. */
-int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, void* stream);
+ * w fp32 [N, P] -> alpha fp64 [N, P]; alpha_f32 (optional, may be NULL): fp32 [N, P], the same values rounded once -
+ * what examples/main.py:294 obtains with `matrix_alpha.float()` before the bmm. */
+int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, float* alpha_f32, void* stream);
 
 /* examples/main.py:294-296: X[i] = alpha[i] (fp32 [P]) . Z[i] (fp32 [P, D]) -> fp32 [N, D]. */
 int ac_weighted_avg(const float* alpha, const float* Z, int64_t N, int P, int D, float* X, void* stream);

@@ -53,11 +53,11 @@ class ToyOps:
     def empty_packed(self, n, like):
         return ToyPacked(torch.empty(n * like.P, like.D), torch.empty(n * like.P), n, like.P, like.D)
 
-    def max_sq(self, packed_list, device):
-        m = torch.zeros(1)
+    def max_sq(self, packed_list, device, out=None):
+        m = torch.zeros(1) if out is None else out.zero_()
         for pk in packed_list:
             if pk.n:
-                m = torch.maximum(m, pk.sq.max().reshape(1))
+                m.copy_(torch.maximum(m, pk.sq.max().reshape(1)))
         return m
 
     def fixed_shift(self, max_sq_t, n_keys):
@@ -139,13 +139,13 @@ class ToyPrunedOps(ToyOps):
     def nn_slack(self, mk, mq):
         return torch.zeros(3)
 
-    def nn_state(self, nq_rows, device):
+    def nn_state(self, nq_rows, device, overflow=None):
         class State:
             pass
         st = State()
         st.n = nq_rows
         st.best = torch.full((nq_rows,), float("inf"), dtype=torch.float64)
-        st.overflow = torch.zeros(1, dtype=torch.int32)
+        st.overflow = torch.zeros(1, dtype=torch.int32) if overflow is None else overflow.zero_()
         st.overflow_rows = torch.zeros(nq_rows, dtype=torch.int32)
         return st
 
@@ -300,3 +300,76 @@ def test_all_gather_rows_single_process_passthrough():
     from patchcore.pipeline import all_gather_rows
     t = torch.arange(6.0).reshape(3, 2)
     assert all_gather_rows(t, [3]) is t
+
+
+# ------------------------------------------------------------------ several categories as one job (run_categories)
+def _category_items(sizes=(7, 3, 5, 1), n_train=6):
+    g = torch.Generator().manual_seed(23)
+    return [{"images": torch.randn(n, 3, 16, 16, generator=g), "train_images": torch.randn(n_train + c, 3, 16, 16, generator=g)}
+            for c, n in enumerate(sizes)]
+
+
+def _worker_categories(rank, world, init_file, out_dir, mode, schedule, ops_kind, kw):
+    sys.path[:0] = [ROOT, MODELS]
+    from patchcore.pipeline import run_categories
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    ops = ToyPrunedOps(*ops_kind) if ops_kind is not None else ToyOps()
+    outs = run_categories(ops, _category_items(), mode, tau=[1.0, 0.5], train_ratio=1.0, schedule=schedule, **kw)
+    for c, o in enumerate(outs):
+        for tv, res in o["by_tau"].items():
+            np.save(os.path.join(out_dir, "alpha_%d_%d_%s.npy" % (rank, c, tv)), res["alpha"].numpy())
+            np.save(os.path.join(out_dir, "X_%d_%d_%s.npy" % (rank, c, tv)), res["X"])
+            if rank == 0:
+                np.save(os.path.join(out_dir, "pdist_%d_%s.npy" % (c, tv)), res["pdist"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,schedule,ops_kind,kw", [
+    (2, "unsupervised", "pipeline", None, {}),
+    (3, "unsupervised", "pipeline", None, {"budget": 2 * 2 * 12 * 4}),              # sub-blocked steps, odd world, empty shards
+    (4, "unsupervised", "pipeline", None, {"group_images": 3}),                       # several groups of categories
+    (3, "unsupervised", "pipeline", None, {"ring_bytes_all": 1}),                     # rings too large to be in flight together
+    (2, "supervised", "pipeline", None, {}),                                          # ToyOps has no pruned search: exhaustive blocks
+    (3, "supervised", "pipeline", (0, None), {}),                                     # pruned search, no overflow
+    (3, "supervised", "pipeline", (5, [1]), {}),                                      # overflow on ONE rank: every rank joins the second trip
+    (2, "average", "pipeline", None, {}),
+    (3, "unsupervised", "per_gpu", None, {}),
+    (5, "unsupervised", "per_gpu", None, {}),                                         # more ranks than categories: an idle rank
+    (2, "supervised", "per_gpu", (0, None), {}),
+])
+def test_categories_as_one_job_equal_the_per_category_loop(world, mode, schedule, ops_kind, kw):
+    """run_categories - the cross-category pipeline (joint ViT batches, every ring posted up front, step 0 of all
+    categories first, one MAX / SUM / flag all-reduce per group) and the category-per-GPU schedule - gives, on every
+    rank and for every tau, the SAME BITS as run_category called per category on one rank (the reference's loop,
+    examples/main.py:346-366)."""
+    from patchcore.pipeline import run_category, run_categories
+    items = _category_items()
+    ref = [run_category(ToyOps(), it["images"], mode, tau=[1.0, 0.5], train_images=it["train_images"], train_ratio=1.0)
+           for it in items]
+    one = run_categories(ToyPrunedOps(*ops_kind) if ops_kind is not None else ToyOps(), items, mode, tau=[1.0, 0.5],
+                         train_ratio=1.0, schedule="pipeline", **kw)
+    exact = ops_kind is None                      # the toy pruned search takes its minimum in another order of operations
+    for o, r in zip(one, ref):
+        for tv in r["by_tau"]:
+            if exact:
+                np.testing.assert_array_equal(o["by_tau"][tv]["alpha"].numpy(), r["by_tau"][tv]["alpha"].numpy())
+            else:
+                np.testing.assert_allclose(o["by_tau"][tv]["alpha"].numpy(), r["by_tau"][tv]["alpha"].numpy(), rtol=1e-6)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_categories, args=(world, os.path.join(d, "rdzv"), d, mode, schedule, ops_kind, kw), nprocs=world, join=True)
+        for rk in range(world):
+            for c, r in enumerate(ref):
+                for tv, res in r["by_tau"].items():
+                    a = np.load(os.path.join(d, "alpha_%d_%d_%s.npy" % (rk, c, tv)))
+                    X = np.load(os.path.join(d, "X_%d_%d_%s.npy" % (rk, c, tv)))
+                    if exact:
+                        np.testing.assert_array_equal(a, res["alpha"].numpy())
+                        np.testing.assert_array_equal(X, res["X"])
+                    else:
+                        np.testing.assert_allclose(a, res["alpha"].numpy(), rtol=1e-6)
+                        np.testing.assert_allclose(X, res["X"], rtol=1e-5, atol=1e-6)
+        if exact:
+            for c, r in enumerate(ref):
+                for tv, res in r["by_tau"].items():
+                    np.testing.assert_array_equal(np.load(os.path.join(d, "pdist_%d_%s.npy" % (c, tv))), res["pdist"].numpy())

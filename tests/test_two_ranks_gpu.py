@@ -174,3 +174,110 @@ def test_pruned_search_gives_up_on_tie_heavy_banks_across_shards(dev):
             lo, hi = bounds[r]
             assert np.array_equal(np.load(os.path.join(d, "w_%d.npy" % r)), ref["w_loc"][lo:hi].cpu().numpy()), r
             assert np.array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].cpu().numpy()), r
+
+
+def _worker_empty_shard_overflow(rank, world, init_file, out_dir):
+    sys.path[:0] = [ROOT, MODELS, os.path.join(ROOT, "tests")]
+    from patchcore.pipeline import HipOps, run_category
+    from _synth import clustered_embeddings
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    ops.nn_cap = 1
+    Zs, _ = clustered_embeddings(2, 100, 256, 2, salt=61)
+    Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=62)
+    Zb = np.repeat(Zb[:1], 6, axis=0)
+    out = run_category(ops, torch.from_numpy(Zs).to(dev), "supervised", tau=1.0, train_images=torch.from_numpy(Zb).to(dev),
+                       train_ratio=3.0)
+    np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overflow_with_an_empty_query_shard(dev):
+    """Round-3 advice: 2 test images over 3 ranks (rank 2 holds NO query image), a bank of six copies of one image and
+    one candidate slot, so every query of ranks 0 and 1 overflows.  The flag is MAX all-reduced, so rank 2 enters the
+    overflow branch too - with zero-size tensors - and must carry the bank shards round the second ring instead of
+    raising (which left the other ranks waiting in batch_isend_irecv).  Result = the exhaustive one-rank path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patchcore.pipeline import HipOps, run_category
+    from _synth import clustered_embeddings
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    Zs, _ = clustered_embeddings(2, 100, 256, 2, salt=61)
+    Zb, _ = clustered_embeddings(5, 100, 256, 1, salt=62)
+    Zb = np.repeat(Zb[:1], 6, axis=0)
+    ref = run_category(ops, torch.from_numpy(Zs).to(dev), "supervised", tau=1.0, train_images=torch.from_numpy(Zb).to(dev),
+                       train_ratio=3.0, prune=False)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_empty_shard_overflow, args=(3, os.path.join(d, "rdzv"), d), nprocs=3, join=True)
+        for r in range(3):
+            assert np.array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].cpu().numpy()), r
+
+
+def _worker_categories_gpu(rank, world, init_file, out_dir, mode, schedule):
+    sys.path[:0] = [ROOT, MODELS, os.path.join(ROOT, "tests")]
+    from patchcore.pipeline import HipOps, run_categories
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    ops.embed_many = lambda sets: [x.contiguous() for x in sets]
+    outs = run_categories(ops, _engine_items(dev), mode, tau=1.0, train_ratio=1.0, schedule=schedule)
+    for c, o in enumerate(outs):
+        np.save(os.path.join(out_dir, "alpha_%d_%d.npy" % (rank, c)), o["alpha"].cpu().numpy())
+        np.save(os.path.join(out_dir, "X_%d_%d.npy" % (rank, c)), o["X"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _engine_items(dev):
+    from _synth import clustered_embeddings
+    items = []
+    for c, (n, m) in enumerate([(7, 5), (3, 4), (5, 6)]):
+        Zs, _ = clustered_embeddings(n, 100, 256, 3, salt=70 + c)
+        Zb, _ = clustered_embeddings(m, 100, 256, 1, salt=80 + c)
+        items.append({"images": torch.from_numpy(Zs).to(dev), "train_images": torch.from_numpy(Zb).to(dev)})
+    return items
+
+
+@pytest.mark.parametrize("world,mode,schedule", [(2, "unsupervised", "pipeline"), (3, "supervised", "pipeline"),
+                                                 (3, "unsupervised", "per_gpu")])
+def test_categories_as_one_job_match_the_loop_bitwise(dev, world, mode, schedule):
+    """run_categories on the real kernels (embeddings given): the cross-category pipeline - every ring of the group in
+    flight, step 0 of all categories first, ONE all-reduce of all maxima / all int64 sums / all overflow flags - and the
+    category-per-GPU schedule, on 2-3 real ranks sharing the GPU, are BIT-EQUAL to run_category per category on one rank."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patchcore.pipeline import HipOps, run_category, run_categories
+    ops = HipOps(core=None)
+    ops.embed = lambda images: images.contiguous()
+    ops.embed_many = lambda sets: [x.contiguous() for x in sets]
+    items = _engine_items(dev)
+    ref = [run_category(ops, it["images"], mode, tau=1.0, train_images=it["train_images"], train_ratio=1.0) for it in items]
+    one = run_categories(ops, items, mode, tau=1.0, train_ratio=1.0)
+    for o, r in zip(one, ref):
+        assert torch.equal(o["alpha"], r["alpha"]) and np.array_equal(o["X"], r["X"])
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_categories_gpu, args=(world, os.path.join(d, "rdzv"), d, mode, schedule), nprocs=world, join=True)
+        for rk in range(world):
+            for c, r in enumerate(ref):
+                assert np.array_equal(np.load(os.path.join(d, "alpha_%d_%d.npy" % (rk, c))), r["alpha"].cpu().numpy()), (rk, c)
+                assert np.array_equal(np.load(os.path.join(d, "X_%d_%d.npy" % (rk, c))), r["X"]), (rk, c)
+
+
+def test_joint_vit_batches_match_per_category_batches(dev):
+    """embed_device_many: three image sets through the ViT as one stream of batches of 4 (batches span the set
+    boundaries through the staging buffer) against embed_device per set."""
+    core = _build(dev)
+    test, train = _images()
+    sets = [test[:3].to(dev), train[:5].to(dev), test[3:].to(dev), test[:0].to(dev)]
+    Zs = core.embed_device_many(sets, batch_size=4)
+    assert [z.shape[0] for z in Zs] == [3, 5, 4, 0]
+    for s, z in zip(sets[:3], Zs):
+        ref = core.embed_device(s, batch_size=4)
+        # the same image in a batch of another size takes another tile path in the GEMMs only if the kernels differ in
+        # their K order - they do not (tests/test_gemm_generations_gpu.py): bit-equal
+        assert torch.equal(z, ref)
