@@ -15,6 +15,10 @@ Conscious differences:
   * images are embedded in batches and stay on the device; the normal-image bank of the
     supervised mode is a seeded permutation (reference: unseeded shuffle, main.py:274).
   * launched under torchrun, the images of each category are sharded over the ranks (RCCL).
+  * the categories run as ONE job (``--category_schedule pipeline``, pipeline.run_categories): the rank's images of all
+    categories share full ViT batches, every ring of shards is in flight before the alpha work starts.
+    ``sequential`` is the reference's category-by-category loop (main.py:346-366), ``per_gpu`` gives whole categories
+    to GPUs.  The artefacts are the same files with the same contents.
 Run with ``PYTHONPATH=../models python main.py ...`` exactly like the reference.
 """
 import argparse
@@ -38,7 +42,7 @@ import patchcore.sampler  # noqa: E402
 import patchcore.datasets.mvtec as mvtec  # noqa: E402
 import patchcore.datasets.synthetic as synthetic  # noqa: E402
 from patchcore.patchcore import AnomalyClusteringCore  # noqa: E402
-from patchcore.pipeline import HipOps, run_category, select_bank, shard_bounds  # noqa: E402
+from patchcore.pipeline import HipOps, run_categories, run_category, select_bank, shard_bounds  # noqa: E402
 
 device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu")
 
@@ -61,10 +65,9 @@ def _dataset(path, category, split, dataset):
                                            classname=category, resize=256, imagesize=224)
 
 
-def make_category_data(path, category, pretrain_embed_dimension, target_embed_dimension, backbone_names,
-                       layers_to_extract_from, patchsize, save_path, train_ratio=1.0, tau=1, supervised="unsupervised",
-                       dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=32, cache=None):
-    print("{:-^80}".format(category + ' start ' + supervised))
+def _build_core(backbone_names, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension, patchsize,
+                backbone=None):
+    """The model half of make_category_data (main.py:198-252): backbone -> AnomalyClusteringCore.load."""
     faiss_on_gpu = True
     faiss_num_workers = 4
     input_shape = (3, 224, 224)
@@ -72,9 +75,6 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
     sampler = patchcore.sampler.IdentitySampler()
     backbone_seed = None
     backbone_name = backbone_names[0]
-
-    test_dataset = _dataset(path, category, mvtec.DatasetSplit.TEST, dataset)
-
     if len(backbone_names) > 1:
         coll = [[] for _ in range(len(backbone_names))]
         for layer in layers_to_extract_from:
@@ -83,48 +83,60 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
     else:
         coll = [layers_to_extract_from]
     layers_to_extract_from = coll[0]
-
     if ".seed-" in backbone_name:
         backbone_name, backbone_seed = backbone_name.split(".seed-")[0], int(backbone_name.split("-")[-1])
     if backbone is None:
         backbone = patchcore.backbones.load(backbone_name)
     backbone.name, backbone.seed = backbone_name, backbone_seed
-
     nn_method = patchcore.common.FaissNN(faiss_on_gpu, faiss_num_workers)
     core = AnomalyClusteringCore(device)
     core.load(backbone=backbone, layers_to_extract_from=layers_to_extract_from, device=device,
               input_shape=input_shape, pretrain_embed_dimension=pretrain_embed_dimension,
               target_embed_dimension=target_embed_dimension, patchsize=patchsize, featuresampler=sampler,
               anomaly_scorer_num_nn=anomaly_scorer_num_nn, nn_method=nn_method)
+    return core, layers_to_extract_from
 
-    # ONE pass over each split: decode on the host, resize / crop / normalise on the GPU, and collect the per-image
-    # records (what test.py reads as `info`: the item dicts minus pixels, collated with batch size 1) on the way.
-    # The reference walks the test set twice with batch size 1 (main.py:254-262, :266).
-    # `cache` (a dict the caller keeps per category): the loaded test set and its embeddings Z are the same for
-    # every mode, so `--supervised both` decodes and embeds the test images once.
-    # Launched under torchrun, a rank decodes only the files of its own image shard (records of all).
-    cache = {} if cache is None else cache
+
+def _ranks():
     multi = dist.is_available() and dist.is_initialized()
-    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    return (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+
+
+def _load_test(path, category, dataset, cache, whole=False):
+    """ONE pass over the test split: decode on the host, resize / crop / normalise on the GPU, and collect the per-image
+    records (what test.py reads as `info`: the item dicts minus pixels, collated with batch size 1) on the way.
+    The reference walks the test set twice with batch size 1 (main.py:254-262, :266).  `cache` (a dict the caller keeps
+    per category): the loaded test set and its embeddings Z are the same for every mode, so `--supervised both`
+    decodes and embeds the test images once.  Launched under torchrun, a rank decodes only the files of its own
+    image shard (records of all); whole=True: all of them (a rank that may be given the WHOLE category)."""
+    rank, world = _ranks()
     if "images" not in cache:
+        test_dataset = _dataset(path, category, mvtec.DatasetSplit.TEST, dataset)
+        cache["n_test"] = len(test_dataset)
         cache["images"], cache["info"] = test_dataset.load_category(
-            device, only=shard_bounds(len(test_dataset), world)[rank] if world > 1 else None)
-    images, info = cache["images"], cache["info"]
-    train_images = None
-    if supervised == "supervised":
-        train_ds = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset)
-        only = None
-        if world > 1:                               # the bank images this rank embeds: its slice of the seeded selection
-            sel = select_bank(len(train_ds), len(test_dataset), train_ratio, 0)
-            blo, bhi = shard_bounds(len(sel), world)[rank]
-            only = set(int(i) for i in sel[blo:bhi])
-        train_images, _ = train_ds.load_category(device, only=only)
-    out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
-                       train_images=train_images, train_ratio=train_ratio, want_pdist=False, Z_loc=cache.get("Z_loc"))
-    cache["Z_loc"] = out["Z_loc"]
-    # `tau` may be a list (a sweep): embeddings and patch distances were computed once; one artefact per tau
+            device, only=shard_bounds(len(test_dataset), world)[rank] if (world > 1 and not whole) else None)
+    return cache["images"], cache["info"]
+
+
+def _load_bank(path, category, dataset, n_test, train_ratio, whole=False):
+    """The train images the supervised mode may select (main.py:269-281); under torchrun only this rank's slice of
+    the seeded selection is decoded."""
+    rank, world = _ranks()
+    train_ds = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset)
+    only = None
+    if world > 1 and not whole:                     # the bank images this rank embeds: its slice of the seeded selection
+        sel = select_bank(len(train_ds), n_test, train_ratio, 0)
+        blo, bhi = shard_bounds(len(sel), world)[rank]
+        only = set(int(i) for i in sel[blo:bhi])
+    train_images, _ = train_ds.load_category(device, only=only)
+    return train_images
+
+
+def _save(out, info, category, supervised, tau, save_path, layers_to_extract_from, pretrain_embed_dimension,
+          target_embed_dimension, train_ratio, info_dir):
+    """torch.save((alpha, X)) per tau under the reference's path scheme (main.py:298-309) + the info records."""
     taus = list(tau) if isinstance(tau, (list, tuple)) else [tau]
-    rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    rank0 = _ranks()[0] == 0
     data_matrix = None
     for tv in taus:
         res = out["by_tau"][float(tv)]
@@ -138,8 +150,63 @@ def make_category_data(path, category, pretrain_embed_dimension, target_embed_di
     if rank0 and info_dir is not None:
         os.makedirs(info_dir, exist_ok=True)
         torch.save(info, os.path.join(info_dir, "info_" + category + ".pickle"))
+    return data_matrix
+
+
+def make_category_data(path, category, pretrain_embed_dimension, target_embed_dimension, backbone_names,
+                       layers_to_extract_from, patchsize, save_path, train_ratio=1.0, tau=1, supervised="unsupervised",
+                       dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=32, cache=None):
+    """One category, as the reference runs it (main.py:183-311)."""
+    print("{:-^80}".format(category + ' start ' + supervised))
+    core, layers = _build_core(backbone_names, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension,
+                               patchsize, backbone)
+    cache = {} if cache is None else cache
+    images, info = _load_test(path, category, dataset, cache)
+    train_images = _load_bank(path, category, dataset, cache["n_test"], train_ratio) if supervised == "supervised" else None
+    out = run_category(HipOps(core, batch_size=batch_size), images, supervised, tau=tau, k=1,
+                       train_images=train_images, train_ratio=train_ratio, want_pdist=False, Z_loc=cache.get("Z_loc"))
+    cache["Z_loc"] = out["Z_loc"]
+    # `tau` may be a list (a sweep): embeddings and patch distances were computed once; one artefact per tau
+    data_matrix = _save(out, info, category, supervised, tau, save_path, layers, pretrain_embed_dimension,
+                        target_embed_dimension, train_ratio, info_dir)
     print("{:-^80}".format(category + ' end'))
     return data_matrix
+
+
+def make_categories_data(path, categories, pretrain_embed_dimension, target_embed_dimension, backbone_names,
+                         layers_to_extract_from, patchsize, save_paths, train_ratio=1.0, tau=1, modes=("unsupervised",),
+                         dataset="mvtec_ad", info_dir=None, backbone=None, batch_size=128, schedule="pipeline"):
+    """All categories as ONE job per mode (pipeline.run_categories) - the same artefacts as make_category_data per
+    category (the reference's loop, main.py:346-366).  save_paths: {mode: folder}.  -> {(mode, category): (alpha, X)}."""
+    core, layers = _build_core(backbone_names, layers_to_extract_from, pretrain_embed_dimension, target_embed_dimension,
+                               patchsize, backbone)
+    ops = HipOps(core, batch_size=batch_size)
+    whole = schedule == "per_gpu"                       # a rank may be handed any WHOLE category
+    caches = [{} for _ in categories]
+    items = []
+    for category, cache in zip(categories, caches):
+        print("{:-^80}".format(category + ' load'))
+        images, _ = _load_test(path, category, dataset, cache, whole=whole)
+        items.append({"images": images, "train_images": None})
+    results = {}
+    Z_locs = None
+    for supervised in modes:
+        print("{:-^80}".format("%d categories start %s" % (len(categories), supervised)))
+        if supervised == "supervised":
+            for category, cache, it in zip(categories, caches, items):
+                it["train_images"] = _load_bank(path, category, dataset, cache["n_test"], train_ratio, whole=whole)
+        outs = run_categories(ops, items, supervised, tau=tau, k=1, train_ratio=train_ratio, want_pdist=False,
+                              schedule=schedule, Z_locs=Z_locs if schedule != "per_gpu" else None)
+        if schedule != "per_gpu":
+            Z_locs = [o["Z_loc"] for o in outs]       # Z does not depend on the mode: the next mode embeds only its bank
+        for category, cache, o in zip(categories, caches, outs):
+            results[(supervised, category)] = _save(o, cache["info"], category, supervised, tau, save_paths[supervised],
+                                                    layers, pretrain_embed_dimension, target_embed_dimension, train_ratio,
+                                                    info_dir)
+        for it in items:
+            it["train_images"] = None
+        print("{:-^80}".format("%d categories end" % len(categories)))
+    return results
 
 
 def build_parser():
@@ -161,6 +228,9 @@ def build_parser():
     parser.add_argument('--dataset', default='mvtec_ad', type=str, help="Dataset to use (mvtec_ad | synthetic).")
     parser.add_argument('--categories', nargs='*', default=None, help="Subset of categories (default: all 15).")
     parser.add_argument('--batch_size', type=int, default=32, help="Images per ViT launch.")
+    parser.add_argument('--category_schedule', default="pipeline", choices=["pipeline", "sequential", "per_gpu"],
+                        help="pipeline: all categories as one job (pipeline.run_categories); sequential: one category "
+                             "after another, as the reference loops them; per_gpu: whole categories to GPUs.")
     return parser
 
 
@@ -170,7 +240,9 @@ def main(argv=None):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         torch.cuda.set_device(device)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        import datetime
+        # explicit timeout: a rank that dies or hangs ends the job after two minutes instead of never
+        dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=120))
         probe = torch.ones(1, device=device)             # RCCL smoke before any work: a 1-element all-reduce
         dist.all_reduce(probe)
         if int(probe.item()) != dist.get_world_size():
@@ -183,7 +255,18 @@ def main(argv=None):
         os.makedirs(save_path, exist_ok=True)
         with open(os.path.join(save_path, "WEIGHTS_SOURCE.txt"), "w") as f:     # random-init runs stay recognisable
             f.write(str(getattr(backbone, "weights_source", "unknown")) + "\n")
-    for category in (args.categories or _CLASSNAMES):
+    categories = list(args.categories or _CLASSNAMES)
+    info_dir = args.output_dir + "/" + args.dataset + "/info"
+    if args.category_schedule != "sequential" and len(categories) > 1:
+        save_paths = {m: args.output_dir + "/" + args.dataset + "/" + args.backbone_names[0] + "/" + m for m in modes}
+        return make_categories_data(
+            path=args.path, categories=categories, pretrain_embed_dimension=args.pretrain_embed_dimension,
+            target_embed_dimension=args.target_embed_dimension, backbone_names=args.backbone_names,
+            layers_to_extract_from=args.layers_to_extract_from, patchsize=args.patchsize, save_paths=save_paths,
+            train_ratio=args.train_ratio, tau=(args.tau_list if args.tau_list else args.tau), modes=modes,
+            dataset=args.dataset, info_dir=info_dir, backbone=backbone, batch_size=args.batch_size,
+            schedule=args.category_schedule)
+    for category in categories:
         cache = {}                                       # test images + embeddings shared by the modes of a category
         for supervised in modes:
             save_path = args.output_dir + "/" + args.dataset + "/" + args.backbone_names[0] + "/" + supervised
@@ -193,7 +276,7 @@ def main(argv=None):
                 layers_to_extract_from=args.layers_to_extract_from, patchsize=args.patchsize, save_path=save_path,
                 tau=(args.tau_list if args.tau_list else args.tau), train_ratio=args.train_ratio,
                 supervised=supervised, dataset=args.dataset,
-                info_dir=args.output_dir + "/" + args.dataset + "/info", backbone=backbone,
+                info_dir=info_dir, backbone=backbone,
                 batch_size=args.batch_size, cache=cache)
     return results
 

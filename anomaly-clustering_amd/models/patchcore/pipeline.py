@@ -713,7 +713,7 @@ def _groups(sizes, limit):
 def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ratio=1.0, group=None, bank_seed=0,
                    want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
                    prune=True, schedule="pipeline", group_images=GROUP_IMAGES, ring_bytes_all=RING_BYTES_ALL,
-                   costs=None, solo=False):
+                   costs=None, solo=False, Z_locs=None):
     """Several categories as ONE job.  items: [{"images": [N_c, 3, H, W], "train_images": bank candidates or None}].
     Returns [run_category's dict per category]; the numbers are those of the per-category loop the reference runs
     (examples/main.py:346-366) - bit for bit given the same embeddings - only the ORDER of the work changes:
@@ -735,7 +735,9 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
            as the alternative to the image-sharded schedule north_star specifies.
 
     Categories are taken in groups of at most `group_images` images per rank (Z + packed copy: 25.7 MB per image).
-    solo: this rank works ALL of `items` alone although a process group exists (how "per_gpu" runs a rank's share)."""
+    solo: this rank works ALL of `items` alone although a process group exists (how "per_gpu" runs a rank's share).
+    Z_locs: the rank's test-set embeddings of EVERY category from an earlier call (out[c]["Z_loc"]; "pipeline" and
+    "sequential" only): a second mode on the same images embeds only its bank."""
     rank, world = (0, 1) if solo else _world(group)
     mark = _marker(ops, timings)
     ncat = len(items)
@@ -744,14 +746,19 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
     if supervised == "supervised" and any(it.get("train_images") is None for it in items):
         raise ValueError("supervised alpha needs train_images for every category")
 
-    def one(it):
+    if Z_locs is not None and (len(Z_locs) != ncat or any(z is None for z in Z_locs)):
+        raise ValueError("Z_locs must hold the embeddings of every category")
+
+    def one(c):
+        it = items[c]
         return run_category(ops, it["images"], supervised, tau=tau, k=k, train_images=it.get("train_images"),
+                            Z_loc=Z_locs[c] if Z_locs is not None else None,
                             train_ratio=train_ratio, group=group, bank_seed=bank_seed, want_pdist=want_pdist,
                             want_host=want_host, timings=timings, budget=budget, remote_bytes=remote_bytes, prune=prune,
                             solo=solo)
 
     if schedule == "sequential":
-        return [one(it) for it in items]
+        return [one(c) for c in range(ncat)]
     if schedule == "per_gpu":
         return _run_categories_per_gpu(ops, items, supervised, tau, k, train_ratio, group, bank_seed, want_pdist,
                                        want_host, timings, budget, prune, costs, group_images)
@@ -772,14 +779,22 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
     for grp in _groups(per_rank, group_images):
         # ---- 1. one stream of ViT batches for the group
         t0 = time.perf_counter()
-        sets = [items[c]["images"][all_bounds[c][rank][0]: all_bounds[c][rank][1]] for c in grp]
+        sets = []
+        if Z_locs is None:
+            sets = [items[c]["images"][all_bounds[c][rank][0]: all_bounds[c][rank][1]] for c in grp]
+        else:
+            for c in grp:
+                if Z_locs[c].shape[0] != all_bounds[c][rank][1] - all_bounds[c][rank][0]:
+                    raise ValueError("Z_locs[%d] holds %d images, this rank's shard has %d"
+                                     % (c, Z_locs[c].shape[0], all_bounds[c][rank][1] - all_bounds[c][rank][0]))
+        ntest = len(sets)
         if supervised == "supervised":
             for c in grp:
                 blo, bhi = bank_bounds[c][rank]
                 sets.append(items[c]["train_images"][sels[c][blo:bhi]])
-        Zs = _embed_sets(ops, sets)
-        Z = {c: Zs[i] for i, c in enumerate(grp)}
-        Zb = {c: Zs[len(grp) + i] for i, c in enumerate(grp)} if supervised == "supervised" else {}
+        Zs = _embed_sets(ops, sets) if sets else []
+        Z = {c: (Zs[i] if Z_locs is None else Z_locs[c]) for i, c in enumerate(grp)}
+        Zb = {c: Zs[ntest + i] for i, c in enumerate(grp)} if supervised == "supervised" else {}
         del Zs
         mark("embed", t0)
         device = Z[grp[0]].device

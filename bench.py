@@ -67,6 +67,16 @@ def parse():
     ap.add_argument("--tau", type=float, default=1.0)
     ap.add_argument("--budget-mb", type=int, default=1024, help="memory budget of one matrix of minima")
     ap.add_argument("--schedule", default="auto", choices=["auto", "slices", "ring"])
+    ap.add_argument("--category-schedule", default="pipeline", choices=["pipeline", "sequential", "per_gpu"],
+                    help="configs 3 / 4: the 15 categories as ONE job (joint ViT batches, every ring in flight, the local "
+                         "blocks of all categories first; default), one after another as the reference loops them, or whole "
+                         "categories to GPUs by longest-processing-time-first")
+    ap.add_argument("--launch-timeout", type=float, default=None,
+                    help="self-launched ranks (--gpus N without torchrun): wall-clock limit in seconds after which the "
+                         "children are ended BY PID and the launcher returns 124 (default: 480 s, config 5: 3300 s)")
+    ap.add_argument("--collective-timeout", type=float, default=None,
+                    help="timeout of the process group in seconds (default: 120 s, config 5: 3600 s - a collective queued "
+                         "behind minutes of MFMA work completes that late)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, nargs="+", default=[32, 83],
                     help="category sizes at which the CPU baseline is MEASURED (N=83 takes about a minute of host time)")
@@ -176,12 +186,16 @@ def cpu_baseline(sizes, n_quote, category, probe_n=8):
     torch.set_num_threads(default_threads)
     at_size = [r for r in runs if r["n"] == n_quote]
     head = at_size[0] if at_size else runs[-1]
+    worse = [th for th in sweep if th > best and sweep[th] > 1.05 * sweep[best]]
     out = {"value": head["images_per_sec"], "unit": "images/sec", "cores": best, "threads": best, "kind": "port",
            "sample": "MEASURED: N=%d images of the %s-shaped category end to end on the host (ViT+aggregate batch 1, all "
                      "%d ordered alpha pairs, weighted average, pdist) at %d torch threads = best of the sweep %s (seconds "
-                     "for a %d-image probe: %d ordered pairs)"
+                     "for a %d-image probe: %d ordered pairs). `cores` = `threads` = the torch threads USED (the bench "
+                     "contract's meaning), not the machine's core count: that is `physical_cores`.%s"
                      % (head["n"], cat, head["n"] * (head["n"] - 1), best, {k: round(v, 2) for k, v in sweep.items()},
-                        probe.shape[0], probe.shape[0] * (probe.shape[0] - 1)),
+                        probe.shape[0], probe.shape[0] * (probe.shape[0] - 1),
+                        (" The sweep gets SLOWER beyond %d threads (%s): the box's cores are shared with other tenants or "
+                         "the probe is too small to feed them; more threads were tried and lost." % (best, worse)) if worse else ""),
            "n": head["n"], "seconds": head["seconds"], "s_per_image": head["s_per_image"], "s_per_pair": head["s_per_pair"],
            "measured_sizes": runs,
            "one_thread": {"n": 5, "images_per_sec": 5 / (e1 + a1 + t1), "seconds": e1 + a1 + t1},
@@ -237,7 +251,7 @@ def build_workload(args, dev, rank=0, world=1):
                 it["train"] = tr[sel].contiguous()            # M = N_test images: run_category's own selection then keeps all
             items.append(it)
         name = ("MVTec-AD all 15 categories (test-set sizes 83..167, sum N=%d), dino_vitbase8 blocks.10+11, 2048->4096, "
-                "patchsize 3, %s%s, random-init weights, categories one after another"
+                "patchsize 3, %s%s, random-init weights"
                 % (sum(len(i["labels"]) for i in items), mode,
                    " alpha tau=%g" % args.tau if cfg == "3" else " alpha (bank M=N_test per category, train_ratio 1.0)"))
     else:
@@ -271,16 +285,39 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, child_cmd, visible_devices=None, poll_s=0.2):
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT loading the HIP runtime: the KFD topology nodes that have SIMDs
+    (/sys/class/kfd/kfd/topology/nodes/*/properties: CPU nodes say simd_count 0), cut by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.  0 when there is no KFD (no GPU driver)."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                parts = line.split()
+                if len(parts) == 2 and parts[0] == "simd_count" and int(parts[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n, child_cmd, visible_devices=None, poll_s=0.2, timeout_s=480.0):
     """`bench.py --gpus n` started WITHOUT a torchrun environment: start n fresh child processes (one per GPU, the
     same command line each) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's
-    single JSON line on stdout, and return a non-zero code if any child fails (the survivors are ended by PID).
+    single JSON line on stdout, and return a non-zero code if any child fails (the survivors are ended by PID) or
+    if the ranks are still running after timeout_s seconds (a rank HUNG in a collective keeps every rank alive: all
+    are ended by PID, exit code 124).
 
-    The parent never touches the GPU: it only COUNTS devices (torch.cuda.device_count() does not initialise HIP on
-    this image) and never re-execs itself.  Fewer than n visible devices is an error, not a downgrade."""
+    The parent never touches the GPU - it counts devices from the KFD topology in /sys (visible_gpus), not through
+    the runtime - and never re-execs itself.  Fewer than n visible devices is an error, not a downgrade."""
     import subprocess
     if visible_devices is None:
-        visible_devices = torch.cuda.device_count()
+        visible_devices = visible_gpus()
     if visible_devices < n:
         print("bench.py --gpus %d: only %d GPU(s) visible on this node; refusing to run fewer ranks than asked"
               % (n, visible_devices), file=sys.stderr)
@@ -300,11 +337,22 @@ def launch_ranks(n, child_cmd, visible_devices=None, poll_s=0.2):
     reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
     reader.start()
     failed = None
+    deadline = time.monotonic() + timeout_s if timeout_s else None
     while failed is None and any(p.poll() is None for p in procs):
         for r, p in enumerate(procs):
             if p.poll() not in (None, 0):
                 failed = (r, p.returncode)
                 break
+        if failed is None and deadline is not None and time.monotonic() > deadline:
+            alive = [r for r, p in enumerate(procs) if p.poll() is None]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                # this exact child, by PID
+            for p in procs:
+                p.wait()
+            print("bench.py --gpus %d: ranks %s still running after %.0f s (a hung collective?); ended by PID"
+                  % (n, alive, timeout_s), file=sys.stderr)
+            return 124
         time.sleep(poll_s)
     if failed is None:
         for r, p in enumerate(procs):
@@ -344,7 +392,8 @@ def main():
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under torchrun: this process becomes the launcher and makes no GPU call at all
-        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+        limit = args.launch_timeout if args.launch_timeout is not None else (3300.0 if args.config.startswith("5") else 480.0)
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout_s=limit))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -359,7 +408,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        import datetime
+        ct = args.collective_timeout if args.collective_timeout is not None else (3600.0 if args.config.startswith("5") else 120.0)
+        dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=ct))
         # RCCL smoke before anything is timed: communicator creation + a 1-element all-reduce
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)
@@ -374,7 +425,7 @@ def main():
     import patchcore.common as common
     import patchcore.sampler
     from patchcore.patchcore import AnomalyClusteringCore
-    from patchcore.pipeline import HipOps, run_category
+    from patchcore.pipeline import HipOps, run_category, run_categories
 
     os.environ.setdefault("AC_BACKBONE_SEED", "0")       # random-init weights of the named architecture (no checkpoint offline)
     backbone = patchcore.backbones.load("dino_vitbase8")
@@ -392,7 +443,14 @@ def main():
         return run_category(ops, images, mode, tau=args.tau, train_images=it.get("train"), train_ratio=1.0,
                             want_host=False, timings=timings, budget=budget, schedule=args.schedule)
 
+    many = len(items) > 1 and args.category_schedule != "sequential"
+
     def step(timings=None, from_host=False, per_cat=None):
+        if many:                                            # the categories as ONE job (pipeline.run_categories)
+            its = [{"images": it["images_host"].to(dev, non_blocking=True) if from_host else it["images"],
+                    "train_images": it.get("train")} for it in items]
+            return run_categories(ops, its, mode, tau=args.tau, train_ratio=1.0, want_host=False, timings=timings,
+                                  budget=budget, schedule=args.category_schedule)
         outs = []
         for it in items:
             t0 = time.perf_counter()
@@ -483,6 +541,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": name, "baseline_config": args.config, "images_per_step": n_total,
                    "categories": len(items), "vit_batch": args.batch, "alpha_schedule": args.schedule,
+                   "category_schedule": args.category_schedule if len(items) > 1 else None,
                    "minbuf_budget_mb": args.budget_mb,
                    "parallelism": "images of each category sharded over %d rank(s); RCCL all-gather of packed "
                                   "shards / ring of shards, all-gather of X and alpha" % world},
@@ -492,7 +551,7 @@ def main():
         per_cat, stages = [], {}
         step(timings=stages, per_cat=per_cat)                   # one extra, untimed-for-the-metric step
         out["stage_ms"] = {k: 1e3 * v for k, v in stages.items()}
-        if len(items) > 1:
+        if len(items) > 1 and not many:
             out["per_category"] = [{"category": it["category"], "n": len(it["labels"]), "ms": 1e3 * t,
                                     "images_per_sec": len(it["labels"]) / t} for it, t in zip(items, per_cat)]
         if args.config.startswith("2") or args.config in ("3", "4"):

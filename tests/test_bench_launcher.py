@@ -7,6 +7,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -63,6 +65,39 @@ def test_launcher_fails_when_a_rank_fails_and_ends_the_others(tmp_path, capfd):
     out, err = capfd.readouterr()
     assert rc == 7 and time.time() - t0 < 60
     assert out.strip() == "" and "rank 1 exited with code 7" in err
+
+
+def test_launcher_ends_hung_ranks_at_its_deadline(tmp_path, capfd):
+    """Every rank alive and waiting (a hung collective): no child ever exits, so only the wall-clock limit can end the
+    run - non-zero, within the limit, children ended by PID."""
+    bench = _bench_module()
+    pids = tmp_path / "pids"
+    pids.mkdir()
+    cmd = _stub(tmp_path, """
+        import os, sys, time
+        open(os.path.join(sys.argv[1], os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+    """) + [str(pids)]
+    import time
+    t0 = time.time()
+    rc = bench.launch_ranks(2, cmd, visible_devices=2, timeout_s=3.0)
+    out, err = capfd.readouterr()
+    assert rc == 124 and time.time() - t0 < 30
+    assert out.strip() == "" and "still running after 3 s" in err
+    for r in ("0", "1"):
+        pid = int((pids / r).read_text())
+        with pytest.raises(OSError):
+            os.kill(pid, 0)                                   # the child is gone
+
+
+def test_visible_gpus_reads_no_runtime(monkeypatch):
+    """The launcher's device count comes from the KFD topology in /sys and the *_VISIBLE_DEVICES variables - it never
+    loads the HIP runtime.  This container has no KFD: 0."""
+    bench = _bench_module()
+    n = bench.visible_gpus()
+    assert isinstance(n, int) and n >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
 
 
 def test_launcher_refuses_fewer_devices_than_ranks(tmp_path, capfd):

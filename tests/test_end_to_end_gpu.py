@@ -181,3 +181,28 @@ def test_cli_both_modes_share_one_embedding_pass(tmp_path, dev, monkeypatch):
     assert len(info) == 42 and info[0]["anomaly"] == ["defective"] and info[41]["anomaly"] == ["good"]
     with pytest.raises(FileNotFoundError):                       # a mistyped --path never silently goes synthetic
         main.main(["--path", str(tmp_path / "nope"), "--categories", "toothbrush", "--output_dir", out])
+
+
+def test_cli_categories_as_one_job_write_the_same_artefacts(tmp_path, dev):
+    """`main.py --dataset synthetic --categories toothbrush grid --supervised both` three ways: the categories as ONE
+    job (the default: joint ViT batches over both categories, pipeline.run_categories), one after another (the
+    reference's loop, examples/main.py:346-366) and whole categories per GPU: the same pickles.  A ViT batch that spans
+    the category boundary gives every image the embedding its own batch gives it (the GEMM kernels accumulate each
+    output row in one fixed K order), so the files are equal to the bit."""
+    main, test_mod = _load_examples()
+    argv = ["--dataset", "synthetic", "--categories", "toothbrush", "grid", "--supervised", "both", "--batch_size", "64"]
+    res = {}
+    for sched in ("pipeline", "sequential", "per_gpu"):
+        res[sched] = main.main(argv + ["--output_dir", str(tmp_path / sched), "--category_schedule", sched])
+    keys = {(m, c) for m in ("unsupervised", "supervised") for c in ("toothbrush", "grid")}
+    assert set(res["pipeline"]) == keys and set(res["sequential"]) == keys and set(res["per_gpu"]) == keys
+    for key in keys:
+        a, X = res["sequential"][key]
+        for sched in ("pipeline", "per_gpu"):
+            a1, X1 = res[sched][key]
+            assert torch.equal(a, a1) and np.array_equal(X, X1), (sched, key)
+        mode, cat = key
+        f = "/synthetic/dino_vitbase8/%s/blocks.10_blocks.11_2048_4096_1.0_1.0/matrix_alpha_X_%s_%s.pickle" % (mode, cat, mode)
+        saved = test_mod._safe_load(str(tmp_path / "pipeline") + f)
+        assert torch.equal(saved[0], a) and np.array_equal(saved[1], X)
+    assert len(test_mod._safe_load(str(tmp_path / "pipeline") + "/synthetic/info/info_grid.pickle")) == 78
