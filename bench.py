@@ -449,8 +449,11 @@ def main():
         if many:                                            # the categories as ONE job (pipeline.run_categories)
             its = [{"images": it["images_host"].to(dev, non_blocking=True) if from_host else it["images"],
                     "train_images": it.get("train")} for it in items]
-            return run_categories(ops, its, mode, tau=args.tau, train_ratio=1.0, want_host=False, timings=timings,
+            outs = run_categories(ops, its, mode, tau=args.tau, train_ratio=1.0, want_host=False, timings=timings,
                                   budget=budget, schedule=args.category_schedule)
+            for o in outs:                                  # Z (12.85 MB per image) is not part of the result kept
+                o.pop("Z_loc", None)
+            return outs
         outs = []
         for it in items:
             t0 = time.perf_counter()

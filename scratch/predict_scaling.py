@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
-"""Per-rank COMPUTE time of the image-sharded schedule at G = 1, 2, 4, 8 ranks, measured on ONE MI355X.
+"""Per-rank COMPUTE time of the multi-GPU schedules at G = 1, 2, 4, 8 ranks, MEASURED on ONE MI355X, plus a timeline
+of the ring transfers at an ASSUMED link rate - the prediction DESIGN.md section 6 quotes, for the first multi-GPU
+measurement to be judged against.
 
-Rank 0 of G (a full shard: the slowest rank) embeds its ceil(N/G) images, packs them and walks its own part of the
-unsupervised block schedule (pipeline.unsup_schedule: the symmetric block of its shard + the two-way blocks against
-the G/2 shards it receives) - with the "received" shards taken from a local packed copy of the whole category, so no
-communication happens.  What the 8-GPU run adds on top is listed per G as bytes: the ring transfers (posted up front,
-under the step-0 work), the int64 all-reduce of the sums and the all-gather of X / alpha.  Output: one JSON object
-(profiles/r03_scaling_prediction.json is a committed run) - the prediction DESIGN.md section 6 quotes, for the first
-multi-GPU measurement to be judged against.
+Rank 0 of G (a full shard of every category: the slowest rank) runs exactly the code of pipeline.run_categories /
+run_category - the same jobs (_UnsupJob), the same block launches in the same order - with the "received" shards taken
+from a local packed copy of the whole category, so no communication happens:
 
-    python scratch/predict_scaling.py [--categories bottle pill] [--synthetic-n 2000]
+  sequential   per category: embed the shard (its own ViT batches), pack, ring steps 0 .. G/2 (round 3's schedule)
+  pipeline     embed the shards of ALL categories as one stream of full ViT batches, pack all, step 0 of all
+               categories, then steps 1 .. G/2 category by category (run_categories' order)
+  per_gpu      whole categories to ranks by longest-processing-time-first: the G = 1 per-category times, binned
+
+MEASURED: every *_ms below that is not marked est.  ASSUMED: the xGMI rate (--link-gbs, default 50 GB/s effective
+per link and direction); everything derived from it is marked est.  Re-measure the rate on the first multi-GPU lease
+with `python scratch/p2p_probe.py` (hipMemcpyPeerAsync between two devices) and re-run this script with --link-gbs.
+
+    python scratch/predict_scaling.py --all15            # config 3
+    python scratch/predict_scaling.py --categories bottle
 """
 import argparse
 import json
@@ -24,22 +32,33 @@ os.environ.setdefault("AC_BACKBONE_SEED", "0")
 import torch  # noqa: E402
 
 P, D = 784, 4096
-XGMI_LINK_GBS = 50.0      # assumed EFFECTIVE one-direction rate of one xGMI link for a large P2P copy (spec ~64 raw)
+
+
+class LocalRing:
+    """Stands in for pipeline._Ring: the shard of rank + k is a slice of a local packed copy of the whole category."""
+
+    def __init__(self, pk_all, bounds):
+        self.pk_all, self.bounds = pk_all, bounds
+
+    def get(self, k):
+        lo, hi = self.bounds[k % len(self.bounds)]
+        return self.pk_all.slice(lo, hi) if hi > lo else None
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--categories", nargs="+", default=["bottle", "pill"])
+    ap.add_argument("--categories", nargs="+", default=["bottle"])
     ap.add_argument("--all15", action="store_true")
-    ap.add_argument("--synthetic-n", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--link-gbs", type=float, default=50.0, help="ASSUMED effective one-direction rate of one xGMI link")
+    ap.add_argument("--gpus", type=int, nargs="+", default=[1, 2, 4, 8])
     a = ap.parse_args()
     import acnative
     import patchcore.backbones
     import patchcore.common as common
     import patchcore.sampler
     from patchcore.patchcore import AnomalyClusteringCore
-    from patchcore.pipeline import HipOps, shard_bounds, unsup_schedule, block_images, MEAN, NO_SELF
+    from patchcore.pipeline import HipOps, shard_bounds, _UnsupJob, lpt_assignment
     from patchcore.datasets import synthetic
     dev = torch.device("cuda:0")
     core = AnomalyClusteringCore(dev)
@@ -48,78 +67,141 @@ def main():
               featuresampler=patchcore.sampler.IdentitySampler(), anomaly_scorer_num_nn=5, nn_method=common.FaissNN(True, 4))
     ops = HipOps(core, batch_size=128)
     cats = list(synthetic.TEST_HISTOGRAMS) if a.all15 else a.categories
-    work = [(c, synthetic.category_labels(c)) for c in cats]
-    if a.synthetic_n:
-        kinds = ["good", "a", "b", "c", "d"]
-        work.append(("synthetic", [kinds[(i * 5) // a.synthetic_n] for i in range(a.synthetic_n)]))
+    labels = {c: synthetic.category_labels(c) for c in cats}
+    ns = {c: len(labels[c]) for c in cats}
+    images = {c: synthetic.make_images(c, labels[c]).to(dev) for c in cats}
+    # the whole category packed once: the source of the "received" shards
+    pk_all = {}
+    for c in cats:
+        pk_all[c] = ops.pack(ops.embed(images[c]))
 
-    def sync_time(fn):
+    def timed(fn):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, out
+        return 1e3 * (time.perf_counter() - t0), out
 
-    result = {"assumed_xgmi_link_GBs": XGMI_LINK_GBS, "categories": []}
-    for cat, labels in work:
-        n = len(labels)
-        images = synthetic.make_images(cat, labels)
-        Z = ops.embed(images.to(dev) if n <= 512 else images)
-        pk_all = ops.pack(Z)
-        shift = ops.fixed_shift(ops.max_sq([pk_all], dev), n)
-        row = {"category": cat, "n": n, "per_G": {}}
-        for G in (1, 2, 4, 8):
-            bounds = shard_bounds(n, G)
-            lo, hi = bounds[0]
-            c = block_images(P)
-            sched = list(unsup_schedule(bounds, 0, c))
-            mine = images[lo:hi].to(dev)
+    def jobs_for(G, Z):
+        """One _UnsupJob per category for rank 0 of G, prepared, with the local stand-in ring."""
+        jobs = {}
+        for c in cats:
+            bounds = shard_bounds(ns[c], G)
+            job = _UnsupJob(ops, ops.pack(Z[c]), bounds, 0, G, None, dev)
+            job.m = ops.max_sq([pk_all[c]], dev)                 # what the MAX all-reduce would deliver
+            job.prepare()
+            job.ring = LocalRing(pk_all[c], bounds)
+            jobs[c] = job
+        return jobs
 
-            def rank_step():
-                t_e, Zl = sync_time(lambda: ops.embed(mine))
+    def tail(jobs, Z):
+        for c in cats:
+            w = jobs[c].finish()
+            _, a32 = ops.alpha_softmax(w, 1.0, 1)
+            ops.weighted_avg(a32, Z[c])
+
+    result = {"assumed_xgmi_link_GBs": a.link_gbs, "categories": cats, "n": [ns[c] for c in cats], "per_G": {}}
+    per_cat_1gpu = None
+    for G in a.gpus:
+        shards = {c: images[c][shard_bounds(ns[c], G)[0][0]: shard_bounds(ns[c], G)[0][1]] for c in cats}
+        steps = G // 2
+
+        def run_sequential():
+            t_embed = t_alpha = 0.0
+            per_cat = []
+            for c in cats:
+                te, z = timed(lambda: ops.embed(shards[c]))
                 def alpha():
-                    pk = ops.pack(Zl)
-                    del pk
-                    acc = ops.new_acc(n * P, MEAN, dev)
-                    for it in sched:
-                        if it[0] == "sym":
-                            A = pk_all.slice(*it[2])
-                            ops.pair_accumulate(ops.pair_block(A, A), P, MEAN, 0, shift, acc[it[2][0] * P: it[2][1] * P])
-                        else:
-                            x, y = it[2], it[3]
-                            if x[0] > y[0]:
-                                x, y = y, x
-                            mb, mbt = ops.pair_block(pk_all.slice(*x), pk_all.slice(*y), two_way=True)
-                            ops.pair_accumulate(mb, P, MEAN, NO_SELF, shift, acc[y[0] * P: y[1] * P])
-                            ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[x[0] * P: x[1] * P])
-                    w = ops.pair_finalize(acc[lo * P: hi * P], P, MEAN, n - 1, shift)
-                    al = ops.alpha_softmax(w, 1.0, 1).float().contiguous()
-                    return ops.weighted_avg(al, Zl)
-                t_a, _ = sync_time(alpha)
-                return t_e, t_a
-            rank_step()
-            ts = [rank_step() for _ in range(a.reps)]
-            te, ta = min(t[0] for t in ts), min(t[1] for t in ts)
-            shard_bytes = (hi - lo) * P * (D * 4 + 4)
-            steps = G // 2
-            row["per_G"][G] = {
-                "images_per_rank": hi - lo, "block_launches": len(sched), "embed_ms": 1e3 * te, "alpha_ms": 1e3 * ta,
-                "compute_ms": 1e3 * (te + ta),
-                "ring_shards_received": steps, "ring_bytes_per_shard": shard_bytes if G > 1 else 0,
-                "ring_ms_per_shard_at_assumed_rate": 1e3 * shard_bytes / (XGMI_LINK_GBS * 1e9) if G > 1 else 0.0,
-                "allreduce_bytes": n * P * 8 if G > 1 else 0, "allgather_bytes": n * (D * 4 + P * 4) if G > 1 else 0,
-                "images_per_sec_if_comm_hidden": n / (te + ta)}
-        base = row["per_G"][1]["compute_ms"]
-        for G in (2, 4, 8):
-            row["per_G"][G]["speedup_if_comm_hidden"] = base / row["per_G"][G]["compute_ms"]
-        result["categories"].append(row)
-        del Z, pk_all
+                    jobs = jobs_for_one(c, z)
+                    for k in range(steps + 1):
+                        jobs.run(k)
+                    w = jobs.finish()
+                    _, a32 = ops.alpha_softmax(w, 1.0, 1)
+                    ops.weighted_avg(a32, z)
+                ta, _ = timed(alpha)
+                t_embed += te
+                t_alpha += ta
+                per_cat.append(te + ta)
+            return t_embed, t_alpha, per_cat
+
+        def jobs_for_one(c, z):
+            bounds = shard_bounds(ns[c], G)
+            job = _UnsupJob(ops, ops.pack(z), bounds, 0, G, None, dev)
+            job.m = ops.max_sq([pk_all[c]], dev)
+            job.prepare()
+            job.ring = LocalRing(pk_all[c], bounds)
+            return job
+
+        def run_pipeline():
+            te, Zs = timed(lambda: ops.embed_many([shards[c] for c in cats]))
+            Z = dict(zip(cats, Zs))
+            tp, jobs = timed(lambda: jobs_for(G, Z))                      # pack + norms + accumulators
+            t0s, _ = timed(lambda: [jobs[c].run(0) for c in cats])        # step 0 of all categories
+            later = []
+            for c in cats:                                                # steps >= 1, category by category
+                tc, _ = timed(lambda: [jobs[c].run(k) for k in range(1, steps + 1)])
+                later.append(tc)
+            tt, _ = timed(lambda: tail(jobs, Z))
+            return te, tp, t0s, later, tt
+
+        run_sequential()
+        seq = [run_sequential() for _ in range(a.reps)]
+        best_seq = min(seq, key=lambda r: r[0] + r[1])
+        run_pipeline()
+        pipe = [run_pipeline() for _ in range(a.reps)]
+        bp = min(pipe, key=lambda r: r[0] + r[1] + r[2] + sum(r[3]) + r[4])
+        te, tp, t0s, later, tt = bp
+        if G == 1:
+            per_cat_1gpu = best_seq[2]
+        # ---- ring timeline, est.: category c's `steps` shards travel concurrently (one link each), categories queue
+        shard_mb = [shard_bounds(ns[c], G)[0][1] * P * (D * 4 + 4) / 1e6 for c in cats]
+        ms_per_cat = [mb / (a.link_gbs * 1e3) * 1e3 / 1.0 if G > 1 else 0.0 for mb in shard_mb]   # MB / (GB/s) = ms
+        # sequential: each category's transfer starts after its own embed + pack and hides under its own step 0 only;
+        # take step 0 of a category = its share of t0s (measured jointly), proportional to n^2
+        sq = [ns[c] ** 2 for c in cats]
+        step0 = [t0s * v / sum(sq) for v in sq]
+        exposed_seq = sum(max(0.0, ms_per_cat[i] - step0[i]) for i in range(len(cats))) if G > 1 else 0.0
+        # pipeline: all transfers posted when packing is done; category i has arrived after sum(ms_per_cat[:i+1]);
+        # the compute reaches category i's step 1 at t0s + sum(later[:i])
+        exposed_pipe, clock, arrived = 0.0, t0s, 0.0
+        for i in range(len(cats)):
+            arrived += ms_per_cat[i]
+            if G > 1 and arrived > clock:
+                exposed_pipe += arrived - clock
+                clock = arrived
+            clock += later[i]
+        coll = 0.3 * len(cats) if G > 1 else 0.0                          # est.: 4 small collectives per category
+        coll_pipe = 0.1 + 0.15 * len(cats) if G > 1 else 0.0              # est.: 2 per group + 2 gathers per category
+        n_total = sum(ns.values())
+        seq_ms = best_seq[0] + best_seq[1]
+        pipe_ms = te + tp + t0s + sum(later) + tt
+        result["per_G"][G] = {
+            "images_on_rank0": sum(int(s.shape[0]) for s in shards.values()),
+            "sequential": {"embed_ms": best_seq[0], "alpha_ms": best_seq[1], "compute_ms": seq_ms,
+                           "exposed_ring_ms_est": exposed_seq, "collectives_ms_est": coll,
+                           "step_ms_est": seq_ms + exposed_seq + coll,
+                           "images_per_sec_est": n_total / (seq_ms + exposed_seq + coll) * 1e3},
+            "pipeline": {"embed_ms": te, "pack_ms": tp, "step0_all_ms": t0s, "later_steps_ms": sum(later), "tail_ms": tt,
+                         "compute_ms": pipe_ms, "ring_mb_per_link_total": sum(shard_mb) if G > 1 else 0.0,
+                         "ring_ms_total_est": sum(ms_per_cat), "exposed_ring_ms_est": exposed_pipe,
+                         "collectives_ms_est": coll_pipe, "step_ms_est": pipe_ms + exposed_pipe + coll_pipe,
+                         "images_per_sec_est": n_total / (pipe_ms + exposed_pipe + coll_pipe) * 1e3},
+        }
+        if per_cat_1gpu is not None and len(cats) > 1:
+            table, loads = lpt_assignment(per_cat_1gpu, G)
+            result["per_G"][G]["per_gpu"] = {"max_rank_ms": max(loads), "assignment": table,
+                                             "images_per_sec_est": n_total / max(loads) * 1e3,
+                                             "note": "G = 1 per-category times (measured, sequential) binned by LPT; "
+                                                     "no communication but one all-gather of X / alpha"}
         acnative.release_workspaces()
         torch.cuda.empty_cache()
-    if len(result["categories"]) > 1:
-        tot = {G: sum(r["per_G"][G]["compute_ms"] for r in result["categories"]) for G in (1, 2, 4, 8)}
-        result["sum_over_categories_compute_ms"] = tot
-        result["sum_speedup_if_comm_hidden"] = {G: tot[1] / tot[G] for G in (2, 4, 8)}
+    base_seq = result["per_G"][a.gpus[0]]["sequential"]["step_ms_est"]
+    base_pipe = result["per_G"][a.gpus[0]]["pipeline"]["step_ms_est"]
+    for G in a.gpus:
+        r = result["per_G"][G]
+        r["sequential"]["speedup_est"] = base_seq / r["sequential"]["step_ms_est"]
+        r["pipeline"]["speedup_est"] = base_pipe / r["pipeline"]["step_ms_est"]
+        r["pipeline"]["ideal_compute_ms"] = result["per_G"][a.gpus[0]]["pipeline"]["compute_ms"] / G * a.gpus[0]
     print(json.dumps(result, indent=1))
 
 
