@@ -144,6 +144,140 @@ struct EpiPairMin {
       __builtin_amdgcn_wave_barrier();
     }
   }
+  // ---- fast path of both reductions (round 4).  The general code above spends ~5 000 instructions per wave on
+  // per-element row / column range tests, a second evaluation of d2 and an LDS transpose - 14.5 us per tile during
+  // which the CU's MFMA pipe idles (one workgroup per CU: nothing else is resident), 9 % of the launch
+  // (profiles/r04_allpairs_tile_timing.txt).  A wave block that lies wholly inside the problem, off the diagonal,
+  // with at most one image boundary per side (P >= 64) needs none of that:
+  //   * the norms of the wave's 64 rows arrive as four 16-byte loads (rows 16 mi + 4 g + 0..3 are consecutive),
+  //   * d2 is formed ONCE, in place of the accumulator (same expression, same bits),
+  //   * direction 1 (min over the key rows of an image, per query column): in-lane min over the lane's 16 rows,
+  //     two lane exchanges across the four row groups, then lane (g, c) keeps the column 16 g + c: ONE atomicMin
+  //     wave-instruction on 64 consecutive words per image,
+  //   * direction 2 (min over the key COLUMNS of an image, per row): in-lane min over the lane's 4 column tiles, an
+  //     all-reduce over the 16 lanes of a row group by four DPP row rotations (no LDS), then lane (g, c) keeps the
+  //     row 16 (c >> 2) + 4 g + (c & 3): ONE atomicMin wave-instruction on the wave's 64 consecutive rows per image.
+  // The minima are exact (min is order-free), so the result equals the general path's bit for bit.
+  // Returns false (wave-uniform) when the block does not qualify; the caller then runs the general code.
+  template <int N_ROR>
+  static __device__ inline float row_ror(float v) {      // DPP row_ror:N_ROR inside each group of 16 lanes
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N_ROR, 0xf, 0xf, false));
+  }
+  template <class F>
+  __device__ bool fast(F& f, int m_wave, int n_wave, int lane, bool both_ways) const {
+    static_assert(F::TW == 16 && F::NT == 4 && F::NR == 4, "written for the 16x16x32 accumulator layout");
+    if (m_wave + 64 > M || n_wave + 64 > N || P < 64 || (reinterpret_cast<uintptr_t>(key_sq) & 15)) return false;
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 ks[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(key_sq + m_wave + 16 * mi + 4 * g);
+    float qs[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) qs[ni] = qry_sq[n_wave + 16 * ni + c];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)      // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
+          f.acc[mi][ni][i] = fmaxf((ks[mi][i] - f.acc[mi][ni][i]) + (qs[ni] - f.acc[mi][ni][i]), 0.f);
+    const float inf = __builtin_inff();
+
+    // ---- direction 1: rows are key patches of image r_img (and r_img + 1 from local row br on)
+    const int r_img = m_wave / P;
+    const int br = (r_img + 1) * P - m_wave;            // first local row of the next image; >= 64: no boundary inside
+    {
+      float mn0[4], mn1[4];
+      if (br >= 64) {                                   // wave-uniform
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          float m = inf;
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m = fminf(m, f.acc[mi][ni][i]);
+          mn0[ni] = m;
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { mn0[ni] = inf; mn1[ni] = inf; }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool first = 16 * mi + 4 * g + i < br;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const float v = f.acc[mi][ni][i];
+              mn0[ni] = fminf(mn0[ni], first ? v : inf);
+              mn1[ni] = fminf(mn1[ni], first ? inf : v);
+            }
+          }
+      }
+      float v0 = inf, v1 = inf;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float m = F::min_over_row_groups(mn0[ni]);      // valid in every lane of the column
+        v0 = (g == ni) ? m : v0;
+        if (br < 64) { m = F::min_over_row_groups(mn1[ni]); v1 = (g == ni) ? m : v1; }
+      }
+      unsigned* dst = minbuf + (size_t)r_img * N + n_wave + lane;    // lane (g, c) owns column 16 g + c = lane
+      atomicMin(dst, __float_as_uint(v0));
+      if (br < 64) atomicMin(dst + N, __float_as_uint(v1));
+    }
+    if (!both_ways) return true;
+
+    // ---- direction 2: columns are key patches of image c_img (and c_img + 1 from local column bc on)
+    const int c_img = n_wave / P;
+    const int bc = (c_img + 1) * P - n_wave;
+    {
+      float t0[4][4], t1[4][4];
+      if (bc >= 64) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            t0[mi][i] = fminf(fminf(f.acc[mi][0][i], f.acc[mi][1][i]), fminf(f.acc[mi][2][i], f.acc[mi][3][i]));
+      } else {
+        bool first[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) first[ni] = 16 * ni + c < bc;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float a = inf, b = inf;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              const float v = f.acc[mi][ni][i];
+              a = fminf(a, first[ni] ? v : inf);
+              b = fminf(b, first[ni] ? inf : v);
+            }
+            t0[mi][i] = a;
+            t1[mi][i] = b;
+          }
+      }
+      float v0 = inf, v1 = inf;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float m = t0[mi][i];
+          m = fminf(m, row_ror<8>(m)); m = fminf(m, row_ror<4>(m)); m = fminf(m, row_ror<2>(m)); m = fminf(m, row_ror<1>(m));
+          v0 = (c == 4 * mi + i) ? m : v0;
+          if (bc < 64) {
+            m = t1[mi][i];
+            m = fminf(m, row_ror<8>(m)); m = fminf(m, row_ror<4>(m)); m = fminf(m, row_ror<2>(m)); m = fminf(m, row_ror<1>(m));
+            v1 = (c == 4 * mi + i) ? m : v1;
+          }
+        }
+      // lane (g, c) owns local row 16 (c >> 2) + 4 g + (c & 3): the wave's 64 rows, each once
+      unsigned* dst = minbuf_t + (size_t)c_img * M + m_wave + 16 * (c >> 2) + 4 * g + (c & 3);
+      atomicMin(dst, __float_as_uint(v0));
+      if (bc < 64) atomicMin(dst + M, __float_as_uint(v1));
+    }
+    return true;
+  }
   bool symmetric;        // A == B: only the upper triangle of tiles runs, each reduced both ways into minbuf
   bool two_way;          // A != B, both directions wanted: every tile of the rectangle is reduced both ways
 };
@@ -156,7 +290,11 @@ template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetri
 // panels and ~6 column panels); same-box A/B over 2..16 rows and two tile orders: profiles/r02_raster_ab.txt.
 static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream,
                            int part = 0, int nparts = 1) {
+#ifdef AC_PAIR_GROUP_M
+  const int group_m = AC_PAIR_GROUP_M;       // diagnostic builds (A/B of the L2 window)
+#else
   const int group_m = 6;
+#endif
 #ifdef AC_EXPERIMENTAL
   const int v = epi.two_way ? 0 : ac_gemm_policy();
   if (v == 101 && nparts == 1) return gemm::launch(A, B, M, N, K, epi, stream, 16);
@@ -894,5 +1032,16 @@ extern "C" int ac_debug_wait_times(unsigned long long* out) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm5::ac_wait_times), sizeof(gemm5::ac_wait_times)) != hipSuccess) return -1;
   return 0;
+}
+#endif
+
+#ifdef AC_TILE_TIMING
+// Diagnostic builds only (see gemm_hl2.h): the stamp table of THIS translation unit's gemm2 launches (the all-pairs
+// kernel).  reset != 0 restarts the launch-slot counter; otherwise copies [8 slots][8192 blocks][4 stamps].
+extern "C" int ac_debug_tile_times_alpha(unsigned long long* out, int reset) {
+  if (reset) { gemm2::tt_counter() = 0; return 0; }
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm2::ac_tile_times), sizeof(gemm2::ac_tile_times)) != hipSuccess) return -1;
+  return gemm2::tt_counter();
 }
 #endif

@@ -225,12 +225,16 @@ __global__ void contingency_kernel(const int* __restrict__ a, const int* __restr
 
 // sklearn.metrics.normalized_mutual_info_score (average_method="arithmetic") and adjusted_rand_score from the
 // contingency matrix (sklearn/metrics/cluster/_supervised.py: mutual_info_score, entropy, pair_confusion_matrix).
-constexpr int SCORES_MAX_K = 2048;
+constexpr int SCORES_MAX_K = 4096;
 __global__ void scores_kernel(const unsigned long long* __restrict__ C, int ka, int kb, double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   // One thread (k is a handful on the path; the sums keep sklearn's left-to-right order): the row sums n_c and the
   // column sums n_k are formed ONCE - O(ka kb) for everything below, whatever k.
-  __shared__ double rsum[SCORES_MAX_K], csum[SCORES_MAX_K];
+  // They live in dynamic LDS sized (ka + kb) doubles by the launch: a few dozen bytes on the path, 64 KB at the 4096 cap
+  // (round 3 declared 2 x 2048 doubles of STATIC LDS for this one-thread kernel and halved the public limit to fit).
+  extern __shared__ double sums[];
+  double* rsum = sums;
+  double* csum = sums + ka;
   double N = 0.0, sum_sq = 0.0;
   int rows = 0, cols = 0;
   for (int u = 0; u < ka; ++u) {
@@ -296,7 +300,10 @@ extern "C" int ac_cluster_scores(const int32_t* labels_true, const int32_t* labe
   hipLaunchKernelGGL(contingency_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
                      stream, labels_true, labels_pred, n, k_true, k_pred, reinterpret_cast<unsigned long long*>(contingency),
                      bad_label_flag);
-  hipLaunchKernelGGL(scores_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const unsigned long long*>(contingency),
+  const int lds = (k_true + k_pred) * (int)sizeof(double);
+  if (lds > 48 * 1024)
+    if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&scores_kernel), 2 * SCORES_MAX_K * (int)sizeof(double), nullptr)) return rc;
+  hipLaunchKernelGGL(scores_kernel, dim3(1), dim3(64), lds, stream, reinterpret_cast<const unsigned long long*>(contingency),
                      k_true, k_pred, scores);
   return ac_check_launch("ac_cluster_scores");
 }

@@ -11,6 +11,10 @@
 #include "gemm_hl5.h"
 
 // out[row][col] = relu?( acc * alpha[col] + beta[col] (+ res[row][col]) )
+// nn.ReLU / nn.MaxPool2d propagate a NaN (torch: `x < 0 ? 0 : x`, max with NaN = NaN); fmaxf() returns the non-NaN
+// operand and would turn a poisoned activation into a finite, meaningless feature.  A NaN fails the comparison and is kept.
+__device__ inline float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 struct EpiConvBN {
   const float* alpha; const float* beta; const float* res; float* out; int M, N, relu;
   template <class F>
@@ -28,7 +32,7 @@ struct EpiConvBN {
           if (row < M) {
             float v = f.acc[mi][ni][i] * a + b;
             if (res) v += res[(size_t)row * N + col];
-            out[(size_t)row * N + col] = relu ? fmaxf(v, 0.f) : v;
+            out[(size_t)row * N + col] = relu ? relu_nan(v) : v;
           }
         }
     }
@@ -64,7 +68,7 @@ struct EpiConvBN {
           o0[j] = f.acc[mi][2 * p][j] * a0[j] + b0[j];
           o1[j] = f.acc[mi][2 * p + 1][j] * a1[j] + b1[j];
           if (res) { o0[j] += r0[mi][j]; o1[j] += r1[mi][j]; }
-          if (relu) { o0[j] = fmaxf(o0[j], 0.f); o1[j] = fmaxf(o1[j], 0.f); }
+          if (relu) { o0[j] = relu_nan(o0[j]); o1[j] = relu_nan(o1[j]); }
         }
         if (row < M) {
           float* d = out + (size_t)row * N + col;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float* __restri
       if (ix < 0 || ix >= W) continue;
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + c);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+      for (int j = 0; j < 4; ++j) m[j] = (v[j] > m[j] || v[j] != v[j]) ? v[j] : m[j];   // a NaN pixel wins, as in nn.MaxPool2d
     }
   }
   *reinterpret_cast<f32x4*>(out + pix * C + c) = m;

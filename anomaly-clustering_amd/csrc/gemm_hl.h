@@ -22,10 +22,35 @@ constexpr int FLUSH_STAGES = 16;          // two-level sum: MFMA accumulator flu
 // XCD-aware, grouped rasterisation of a 1-D grid onto (tile_m, tile_n).
 // Blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of the
 // grouped order so that tiles sharing A/B panels share an L2.
+// Blocks are dealt round-robin to the 8 XCDs (block id & 7 names the XCD, id >> 3 its slot there): position of
+// block `id` in the linear tile order.
+//   AC_XCD_WINDOW == 0: every XCD walks ONE contiguous eighth of the order (the 8 XCDs work on 8 far-apart regions;
+//     rounds 1-3).
+//   AC_XCD_WINDOW == W (default 32 = the workgroups one XCD runs at a time): windows of W consecutive tiles are dealt
+//     to the XCDs in turn, so at any time the 8 XCDs work on 8 NEIGHBOURING windows (the same group of tile rows,
+//     adjacent columns): what one XCD misses in its L2 the Infinity Cache already holds for another.  The tail
+//     (total % 8W tiles) keeps the identity order.  Same-box A/B (profiles/r04_allpairs_xcd_window_and_fixup_cost_ab.txt):
+//     all-pairs -0.9 % at N = 83, -1.7 % at N = 167 with W = 32; W = 16 equal, W = 64 / 128 +2 % (slower); the ViT
+//     linear layers do not move.  Results are bit-identical (only the order of the tiles changes).
+#ifndef AC_XCD_WINDOW
+#define AC_XCD_WINDOW 32
+#endif
+__device__ inline int xcd_lin(int id, long long total) {
+  const int xcd = id & 7, slot = id >> 3;
+#if AC_XCD_WINDOW > 0
+  constexpr int W = AC_XCD_WINDOW;
+  const long long full = total / (8 * W) * (8 * W);
+  if (id >= full) return id;
+  return ((slot / W) * 8 + xcd) * W + slot % W;
+#else
+  const int q = (int)(total >> 3), r = (int)(total & 7);
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+#endif
+}
+
 __device__ inline void raster(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
   int total = tiles_m * tiles_n;
-  int q = total >> 3, r = total & 7, xcd = id & 7, slot = id >> 3;
-  int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  int lin = xcd_lin(id, total);
   int per_group = group_m * tiles_n;
   int g = lin / per_group, within = lin - g * per_group;
   int first = g * group_m;

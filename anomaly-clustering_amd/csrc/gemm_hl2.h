@@ -63,9 +63,12 @@ constexpr int FLUSH_STAGES = 16;
 constexpr int TT_SLOTS = 8, TT_BLOCKS = 8192;
 static __device__ unsigned long long ac_tile_times[TT_SLOTS * TT_BLOCKS * 4];
 inline int& tt_counter() { static int c = 0; return c; }
+#ifndef AC_TT_STRIDE
+#define AC_TT_STRIDE 1        // stamp every AC_TT_STRIDE-th workgroup (8: a sample over the whole of a 65 000-tile launch)
+#endif
 #define AC_STAMP(k)                                                                                   \
-  if (tid == 0 && blockIdx.x < gemm2::TT_BLOCKS)                                                   \
-    gemm2::ac_tile_times[((size_t)(stagger & 7) * gemm2::TT_BLOCKS + blockIdx.x) * 4 + (k)] = __builtin_amdgcn_s_memrealtime()
+  if (tid == 0 && blockIdx.x % AC_TT_STRIDE == 0 && blockIdx.x / AC_TT_STRIDE < gemm2::TT_BLOCKS)   \
+    gemm2::ac_tile_times[((size_t)(stagger & 7) * gemm2::TT_BLOCKS + blockIdx.x / AC_TT_STRIDE) * 4 + (k)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define AC_STAMP(k)
 #endif
@@ -118,9 +121,7 @@ __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn
 }
 
 __device__ inline int xcd_chunk_lin(int id, long long total) {
-  // blocks are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of the linear order
-  const int q = (int)(total >> 3), r = (int)(total & 7), xcd = id & 7, slot = id >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  return gemm::xcd_lin(id, total);
 }
 
 // Map a linear tile id to (tm, tn).  Symmetric problems: tiles_m / tiles_n are the full tile counts Tm / Tn and
@@ -318,10 +319,13 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
         // boundaries fall, which is what makes blocked / sharded runs bit-identical to a single launch.
         const bool diag = rb == cb;
         if (rb < cb || (diag && m_wave <= n_wave + 63)) {
-          epi(f, m_wave, n_wave, lane, diag);
-          epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65), diag);
+          // off the diagonal and inside the problem: both reductions from registers (epi.fast); else the general code
+          if (diag || !epi.fast(f, m_wave, n_wave, lane, true)) {
+            epi(f, m_wave, n_wave, lane, diag);
+            epi.transposed(f, m_wave, n_wave, lane, reinterpret_cast<float*>(smem) + wave * (32 * 65), diag);
+          }
         }
-      } else {
+      } else if (!epi.fast(f, m_wave, n_wave, lane, epi.two_way)) {
         epi(f, m_wave, n_wave, lane);
         // two-way rectangle (A and B are different row sets of one symmetric problem): every tile is also
         // reduced the other way, into the epilogue's second matrix

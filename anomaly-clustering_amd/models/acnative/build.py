@@ -71,5 +71,14 @@ def _build(force, verbose, LIB, OBJ_DIR, extra):
     return LIB
 
 
+def build_variant(name, defines, verbose=True):
+    """A diagnostic build libac_hip_<name>.so with extra -D flags (same-box A/B runs: scratch/ab_pairmin.py, AC_LIB=...)."""
+    return _build(True, verbose, LIB[:-3] + "_" + name + ".so", OBJ_DIR + "_" + name, list(defines))
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, experimental="--experimental" in sys.argv)
+    if "--variant" in sys.argv:                          # build.py --variant NAME -DFOO=1 -DBAR=2
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], [f for f in sys.argv[i + 2:] if f.startswith("-D")])
+    else:
+        build(force="--force" in sys.argv, experimental="--experimental" in sys.argv)

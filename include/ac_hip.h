@@ -297,7 +297,7 @@ int ac_ward_linkage(const double* condensed, int64_t n, double* Z, int32_t* bad_
 
 /* Contingency matrix of two integer labelings (values in [0, k_true) / [0, k_pred)) and, from it, sklearn's
  * normalized_mutual_info_score and adjusted_rand_score (examples/test.py:218-219).
- * contingency: uint64 [k_true, k_pred] (out), k <= 2048; scores: float64 [2] = {NMI, ARI}; bad_label_flag: int32 [1],
+ * contingency: uint64 [k_true, k_pred] (out), k <= 4096; scores: float64 [2] = {NMI, ARI}; bad_label_flag: int32 [1],
  * set to 1 when a label lies outside its range (the caller checks it after synchronising). */
 int ac_cluster_scores(const int32_t* labels_true, const int32_t* labels_pred, int64_t n, int k_true, int k_pred,
                       uint64_t* contingency, double* scores, int32_t* bad_label_flag, void* stream);

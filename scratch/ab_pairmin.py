@@ -31,6 +31,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=83)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--no-vendor", action="store_true", help="skip the vendor-library reference GEMMs at the end")
+    ap.add_argument("--one-way", type=lambda v: [int(x) for x in v.split(",") if x], default=[],
+                    help="also time ONE-WAY blocks (all N key images x the first Q query images) on the first library: what "
+                         "re-measuring Q/N of the query patches through the accurate kernel would cost")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -66,6 +70,25 @@ def main():
         t = times[name]
         print("%-12s median %.3f ms  min %.3f  max %.3f  (%.0f TFLOP/s algorithmic at the median)  bit-equal to %s: %s"
               % (name, statistics.median(t), min(t), max(t), flop / statistics.median(t) / 1e9, libs[0][0], same[name]))
+    for q in a.one_way:
+        lib = libs[0][1]
+        mq = torch.empty((a.n, q * P), dtype=torch.int32, device=dev)
+        ts = []
+        for r in range(a.rounds + 1):
+            assert lib.ac_fill_u32(mq.data_ptr(), mq.numel(), INF, st) == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = lib.ac_pair_min_sq_packed(hl.data_ptr(), sq.data_ptr(), a.n, hl.data_ptr(), sq.data_ptr(), q, P, D,
+                                           mq.data_ptr(), None, 0, 1, st)
+            e1.record()
+            assert rc == 0, lib.ac_last_error()
+            torch.cuda.synchronize()
+            if r:
+                ts.append(e0.elapsed_time(e1))
+        print("one-way block, %d key images x %d query images (%.1f %% of the query patches): median %.3f ms  min %.3f"
+              % (a.n, q, 100.0 * q / a.n, statistics.median(ts), min(ts)))
+    if a.no_vendor:
+        return 0
     # vendor reference on the same box: fp16 GEMM through torch (hipBLASLt / rocBLAS), random operands
     # ... and at the shapes of the ViT linear layers at 83 images (qkv, proj, fc1, fc2)
     for (m, n, k) in [(8192, 8192, 8192), (32768, 32768, 4096), (65155, 2304, 768), (65155, 768, 768), (65155, 3072, 768),

@@ -78,6 +78,10 @@ def test_scores_match_sklearn(dev):
         assert np.array_equal(C, metrics.cluster.contingency_matrix(a, b))
         assert abs(nmi - metrics.normalized_mutual_info_score(a, b)) <= 1e-12
         assert abs(ari - metrics.adjusted_rand_score(a, b)) <= 1e-12
+    # many clusters (every image its own cluster and beyond the 48 KB static-LDS size: the sums live in dynamic LDS)
+    a, b = rng.integers(0, 4000, 20000), rng.integers(0, 3500, 20000)
+    nmi, ari, C = acnative.cluster_scores(torch.from_numpy(a.astype(np.int32)).to(dev), torch.from_numpy(b.astype(np.int32)).to(dev), 4000, 3500)
+    assert abs(nmi - metrics.normalized_mutual_info_score(a, b)) <= 1e-10 and abs(ari - metrics.adjusted_rand_score(a, b)) <= 1e-10
     with pytest.raises(ValueError, match="outside"):
         acnative.cluster_scores(torch.tensor([0, 7], dtype=torch.int32, device=dev),
                                 torch.tensor([0, 1], dtype=torch.int32, device=dev), 2, 2)

@@ -192,3 +192,45 @@ def test_patch16_backbone_through_the_whole_embedding(dev, monkeypatch):
     zerr = (Z.cpu() - Z_ref).abs()
     print("patch 16: Z max err %.2e" % zerr.max().item())
     assert torch.all(zerr <= 2e-4 + 2e-4 * Z_ref.abs())
+
+
+@pytest.mark.parametrize("name,width,heads,depth", [("vit_small", 384, 6, 3), ("vit_large", 1024, 16, 2)])
+def test_registered_timm_widths_against_oracle(dev, name, width, heads, depth):
+    """`backbones.load` offers timm's vit_small (C = 384, 6 heads) and vit_large (C = 1024, 16 heads,
+    hidden 4096) (reference backbones.py:34-38), but only C = 768 ran on the GPU.  The ViT kernels at those widths
+    (depth cut to keep the CPU oracle fast: the blocks are identical), two images, every element of the last two taps
+    against the oracle - the gate of test_vit_base8_against_reference_golden_and_oracle - and `_embed` through the
+    aggregator (taps of width C -> 2 x 2048 -> 4096) against the oracle's aggregation."""
+    import patchcore.backbones as backbones
+    import patchcore.common as common
+    import patchcore.sampler
+    import patchcore.vision_transformer as vits
+    from patchcore.patchcore import AnomalyClusteringCore
+    from oracle import vit as ovit, aggregate as oagg
+    timm_name, patch, w, full_depth, h = backbones._TIMM_VIT[name]
+    assert (w, h, patch) == (width, heads, 8)
+    torch.manual_seed(0)
+    model = vits._vit(width, heads, patch, depth=depth, num_classes=0)
+    for p in model.parameters():
+        p.requires_grad = False
+    model = model.eval().to(dev)
+    images = torch.from_numpy(gaussish_tensor((2, 3, 224, 224), salt=21, scale=1.5))
+    taps = (depth - 2, depth - 1)
+    got = _run(model, images.to(dev), taps)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = ovit.forward_taps(sd, images, taps=taps, num_heads=heads)
+    for tap in taps:
+        mine, r = got[tap].cpu(), ref[tap]
+        assert mine.shape == (2, 785, width)
+        err = (mine - r).abs()
+        print("%s block %d: full-tensor max err %.3e (|x| max %.2f)" % (name, tap, err.max().item(), r.abs().max().item()))
+        assert torch.all(err <= ATOL + RTOL * r.abs())
+    core = AnomalyClusteringCore(dev)
+    core.load(backbone=model, layers_to_extract_from=["blocks.%d" % t for t in taps], device=dev, input_shape=(3, 224, 224),
+              pretrain_embed_dimension=2048, target_embed_dimension=4096, patchsize=3,
+              featuresampler=patchcore.sampler.IdentitySampler(), nn_method=common.FaissNN(False, 4))
+    Z = core.embed_device(images.to(dev), batch_size=2).cpu()
+    Zref = oagg.aggregate([ref[taps[0]], ref[taps[1]]], 3, 2048, 4096)[0].reshape(2, 784, 4096)
+    errz = (Z - Zref).abs()
+    print("%s Z: max err %.3e" % (name, errz.max().item()))
+    assert torch.all(errz <= 3e-5 + 2e-5 * Zref.abs())

@@ -83,3 +83,25 @@ def test_embed_through_the_channels_last_aggregation(dev, wrn):
     err = float((Z.cpu() - Zr).abs().max())
     print("Z (standardised per image): max |err| %.2e" % err)
     assert err <= 2e-5
+
+
+def test_nan_pixels_propagate_like_torch(dev, wrn):
+    """Round-3 advice: fmaxf() drops a NaN, so the max pool and the ReLU epilogues used to turn a poisoned pixel into a
+    finite, meaningless feature; nn.MaxPool2d / nn.ReLU (what the reference's torchvision network runs) keep it, and
+    it then reaches cdist / pdist where scipy raises.  A NaN in the input image must poison the same taps as on the
+    CPU restatement (which uses torch's own ops), and leave the other image of the batch untouched."""
+    import patchcore.common as common
+    from oracle import wrn as owrn
+    model, sd = wrn
+    g = torch.Generator().manual_seed(13)
+    images = torch.randn((2, 3, 64, 64), generator=g)
+    images[0, 1, 20, 21] = float("nan")
+    agg = common.NetworkFeatureAggregator(model, ["layer1", "layer2"], dev)
+    out = dict(agg(images.to(dev)))
+    ref = owrn.forward_taps(sd, images, taps=("layer1", "layer2"))
+    for name in ("layer1", "layer2"):
+        mine, r = out[name].cpu(), ref[name]
+        assert torch.equal(torch.isnan(mine), torch.isnan(r)), name
+        assert torch.isnan(mine[0]).any() and not torch.isnan(mine[1]).any()
+        ok = ~torch.isnan(r)
+        assert float((mine[ok] - r[ok]).abs().max()) <= 1e-5 * float(r[ok].abs().max()) + 1e-6
