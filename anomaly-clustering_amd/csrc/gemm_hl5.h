@@ -96,6 +96,18 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
   uint8_t* const Aring = smem;
   uint8_t* const Bring = smem + A_SLOTS * HALF;
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef AC_TILE_TIMING
+  // phase stamps of thread 0 (launch slot in the upper half of group_m): entry, first stage visible, k loop done,
+  // epilogue stores done - read back with ac_debug_tile_times (tests/tile_timing.py)
+  const int tt_slot = (group_m >> 16) & 7;
+  group_m &= 0xffff;
+#define G5_STAMP(k)                                                                                       \
+  if (tid == 0 && blockIdx.x < gemm2::TT_BLOCKS)                                                          \
+    gemm2::ac_tile_times[((size_t)tt_slot * gemm2::TT_BLOCKS + blockIdx.x) * 4 + (k)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define G5_STAMP(k)
+#endif
+  G5_STAMP(0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   constexpr bool SWAP = gemm::HasSwap<Epi>::value;   // accumulate C^T tiles (see gemm_hl.h)
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
   half8 ah = *reinterpret_cast<const half8*>(Aring + a_hi), al = *reinterpret_cast<const half8*>(Aring + a_lo);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   barrier();                                     // B(0) is in registers everywhere: its slot may be refilled
+  G5_STAMP(1);
   auto mfma3 = [&](f32x4& c, const half8& xh, const half8& xl, const half8& yh, const half8& yl) {
     if constexpr (PLAIN) {
       c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, c, 0, 0, 0);
@@ -261,6 +274,7 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
   for (; kt + 3 < nk; ++kt) stage(kt, std::true_type{});
   for (; kt < nk; ++kt) stage(kt, std::false_type{});
   barrier();                                     // ring reads done before an epilogue reuses LDS
+  G5_STAMP(2);
   if constexpr (FLUSH) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -281,6 +295,10 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
   const int m_wave = m0 + wm * 64;
   if constexpr (SWAP && gemm::HasWholeTile<Epi>::value) {
     epi.template swapped_tile<NT>(acc, m_wave, n0 + wn * (NT * 16), lane);
+#ifdef AC_TILE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G5_STAMP(3);
+#endif
     return;
   }
 #pragma unroll
@@ -319,6 +337,10 @@ __global__ __launch_bounds__(threads_of(WN), (WN == 2 ? 1 : WN)) void kernel(con
       epi(f, m_wave, n_wave, lane);
     }
   }
+#ifdef AC_TILE_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  G5_STAMP(3);
+#endif
 }
 
 template <class Epi, int NT = 8, bool FLUSH = false, int WN = 2, bool PLAIN = false>
@@ -354,7 +376,12 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   if (hi <= lo) return AC_OK;
   hipLaunchKernelGGL((kernel<Epi, NT, FLUSH, WN, PLAIN>), dim3((unsigned)(hi - lo)), dim3(THREADS), LDS_BYTES, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
-                     group_m, (int)lo, (int)hi, epi);
+#ifdef AC_TILE_TIMING
+                     group_m | ((gemm2::tt_counter()++ & 7) << 16),
+#else
+                     group_m,
+#endif
+                     (int)lo, (int)hi, epi);
   return ac_check_launch("gemm_hl5");
 }
 

@@ -38,8 +38,8 @@ def main():
         torch.cuda.synchronize()
     buf = np.zeros((8, 8192, 4), dtype=np.uint64)
     n = fn(buf.ctypes.data, 0)
-    names = ["qk", "v", "proj", "fc1", "fc2"]
-    tiles_n = [12, 6, 6, 24, 6]
+    names = ["qkv", "proj", "fc1", "fc2"]            # the block's four linear layers (gemm5, 256x256 tiles)
+    tiles_n = [9, 3, 12, 3]
     tiles_m = (B * 785 + 255) // 256
     print("launches since reset:", n)
     for s, (name, tn) in enumerate(zip(names, tiles_n)):
