@@ -136,7 +136,18 @@ class AnomalyClusteringCore(torch.nn.Module):
         return Z
 
     @torch.no_grad()
-    def embed_device_many(self, image_sets, batch_size=32):
+    def aggregate_taps(self, feats):
+        """The tapped feature maps of some images (as embed_device(..., want_taps=True) returned them, e.g. received
+        from another rank) -> Z fp32 [n, P, D]: the same aggregation kernel on the same bytes, so the same Z bit for bit.
+        A rank sends 4.8 MB of taps per image instead of 12.85 MB of packed Z and the receiver re-aggregates."""
+        n = feats[0].shape[0]
+        Zr, _ = acnative.patch_aggregate(list(feats), self.patch_maker.patchsize,
+                                         self.forward_modules["preprocessing"].output_dim,
+                                         self.forward_modules["preadapt_aggregator"].target_dim)
+        return Zr.reshape(n, Zr.shape[0] // n, Zr.shape[-1])
+
+    @torch.no_grad()
+    def embed_device_many(self, image_sets, batch_size=32, want_taps=False):
         """Several image sets -> [Z_i fp32 [n_i, P, D]] (views of ONE buffer), embedded as one stream of full
         batches: a batch may span set boundaries (its images are then gathered into a staging buffer by
         device-to-device copies; a batch inside one set is read in place).  The reference embeds one image per
@@ -149,6 +160,7 @@ class AnomalyClusteringCore(torch.nn.Module):
         first = next(s for s in image_sets if s.shape[0])
         shape = tuple(first.shape[1:])
         stage = None
+        taps_all = None                                  # want_taps: per layer one [total, ...] buffer, filled batch by batch
         # the row shape of Z is known after the first embedding of this core: Z is then allocated up front and every
         # batch writes in place (the very first call copies its first batch once)
         dims = getattr(self, "_zdims", None)
@@ -172,27 +184,44 @@ class AnomalyClusteringCore(torch.nn.Module):
                     stage[off: off + (b - a)].copy_(image_sets[i][a:b], non_blocking=True)
                     off += b - a
                 chunk = stage[: e - s]
+            got = [] if want_taps else None
             if Z_all is None:
-                z = self._embed(chunk, None, detach=False)
+                z = self._embed(chunk, None, detach=False, taps_out=got)
                 rows, D = z.shape[0] // chunk.shape[0], z.shape[-1]
                 self._zdims = (rows, D)
                 if e == total:
                     Z_all = z.reshape(total, rows, D)
-                    break
-                Z_all = torch.empty((total, rows, D), dtype=torch.float32, device=self.device)
-                Z_all[: e - s].copy_(z.reshape(e - s, rows, D))
+                else:
+                    Z_all = torch.empty((total, rows, D), dtype=torch.float32, device=self.device)
+                    Z_all[: e - s].copy_(z.reshape(e - s, rows, D))
                 del z
             else:
-                self._embed(chunk, None, detach=False, out=Z_all[s:e])
-        return [Z_all[starts[i]: starts[i + 1]] for i in range(len(counts))]
+                self._embed(chunk, None, detach=False, out=Z_all[s:e], taps_out=got)
+            if want_taps:
+                if not all(t.is_contiguous() for t in got):
+                    raise RuntimeError("want_taps needs contiguous feature maps (token maps); this backbone's are strided views")
+                if e - s == total:
+                    taps_all = got                                        # one batch: the maps as the backbone wrote them
+                else:
+                    if taps_all is None:
+                        taps_all = [torch.empty((total,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in got]
+                    for buf, t in zip(taps_all, got):
+                        buf[s:e].copy_(t)
+        Zs = [Z_all[starts[i]: starts[i + 1]] for i in range(len(counts))]
+        if want_taps:
+            return Zs, [[buf[starts[i]: starts[i + 1]] for buf in taps_all] for i in range(len(counts))]
+        return Zs
 
-    def _embed(self, images, supervised, detach=True, provide_patch_shapes=False, out=None):
+    def _embed(self, images, supervised, detach=True, provide_patch_shapes=False, out=None, taps_out=None):
         """Reference :355-431.  `supervised` is accepted and ignored, as upstream.  out (extension): a
-        contiguous fp32 device tensor the rows of Z are written into."""
+        contiguous fp32 device tensor the rows of Z are written into.  taps_out (extension): a list that receives the
+        tapped feature maps of this batch (what the aggregation kernel reads)."""
         _ = self.forward_modules["feature_aggregator"].eval()
         with torch.no_grad():
             taps = self.forward_modules["feature_aggregator"](images)
             feats = [taps[layer] for layer in self.layers_to_extract_from]
+            if taps_out is not None:
+                taps_out.extend(feats)
             Z, patch_shapes = acnative.patch_aggregate(
                 feats, self.patch_maker.patchsize,
                 self.forward_modules["preprocessing"].output_dim,

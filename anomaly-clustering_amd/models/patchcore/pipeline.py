@@ -110,6 +110,28 @@ def unsup_schedule(bounds, rank, c):
                 yield ("two", k, a, b)
 
 
+class Taps:
+    """The tapped feature maps of a block of images ([n, 785, 768] x 2 for ViT-B/8: 4.8 MB per image) - what goes round
+    the ring instead of the packed embeddings (12.85 MB per image): the receiver runs the aggregation kernel on them
+    (17.7 MB of HBM traffic per image, microseconds) and packs the result, bit-identical to what the sender holds.
+    Same surface as a packed block as far as the ring is concerned: n, slice(), tensors()."""
+
+    def __init__(self, feats, n):
+        self.feats, self.n = list(feats), int(n)
+
+    def slice(self, lo, hi):
+        return Taps([f[lo:hi] for f in self.feats], hi - lo)
+
+    def tensors(self):
+        return self.feats
+
+    def bytes_per_image(self):
+        return sum(int(np.prod(f.shape[1:])) * f.element_size() for f in self.feats)
+
+    def empty_like(self, n):
+        return Taps([torch.empty((n,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in self.feats], n)
+
+
 class HipOps:
     """Compute seam backed by libac_hip.so.  Every method raises if the library or the GPU is missing."""
 
@@ -119,26 +141,56 @@ class HipOps:
         self.core = core
         self.batch_size = batch_size
         self._zshape = None
+        self._tapshapes = None
+        # what a multi-rank run sends round the ring: the taps (2.7x fewer bytes) when there is a backbone to tap
+        # (AC_RING_PAYLOAD=packed keeps the packed shards selectable: A/B on the first multi-GPU node)
+        self.ring_payload = "taps" if (core is not None and os.environ.get("AC_RING_PAYLOAD", "taps") == "taps") else None
 
-    def embed(self, images):
+    def _probe(self):
+        probe = torch.ones((1,) + tuple(self.core.input_shape), device=self.core.device)
+        Zs, taps = self.core.embed_device_many([probe], batch_size=1, want_taps=True)
+        self._zshape = tuple(Zs[0].shape[1:])
+        self._tapshapes = [(tuple(t.shape[1:]), t.dtype) for t in taps[0]]
+
+    def _empty(self, want_taps):
+        if self._zshape is None or (want_taps and self._tapshapes is None):
+            self._probe()
+        Z = torch.empty((0,) + self._zshape, dtype=torch.float32, device=self.core.device)
+        if not want_taps:
+            return Z
+        return Z, Taps([torch.empty((0,) + sh, dtype=dt, device=self.core.device) for sh, dt in self._tapshapes], 0)
+
+    def embed(self, images, want_taps=False):
+        """Z fp32 [n, P, D] of the images; want_taps: (Z, Taps of the same images) for the ring."""
         if images.shape[0] == 0:                     # empty shard (fewer images than ranks)
-            if self._zshape is None:
-                probe = torch.ones((1,) + tuple(self.core.input_shape), device=self.core.device)
-                self._zshape = tuple(self.core.embed_device(probe, batch_size=1).shape[1:])
-            return torch.empty((0,) + self._zshape, dtype=torch.float32, device=self.core.device)
+            return self._empty(want_taps)
+        if want_taps:
+            Zs, taps = self.embed_many([images], want_taps=True)
+            return Zs[0], taps[0]
         Z = self.core.embed_device(images, batch_size=self.batch_size)
         self._zshape = tuple(Z.shape[1:])
         return Z
 
-    def embed_many(self, image_sets):
+    def embed_many(self, image_sets, want_taps=False):
         """Several image sets (the rank's shards of several categories) through the ViT as ONE stream of full
         batches: [Z of set 0, Z of set 1, ...], views of one buffer.  A rank of an 8-GPU run holds 5-21 images of
         an MVTec category - a fifth of a ViT batch; the sets of all 15 categories together fill whole batches."""
         if sum(int(s.shape[0]) for s in image_sets) == 0:
-            return [self.embed(s) for s in image_sets]
-        Zs = self.core.embed_device_many(image_sets, batch_size=self.batch_size)
+            res = [self._empty(want_taps) for _ in image_sets]
+            return ([r[0] for r in res], [r[1] for r in res]) if want_taps else res
+        out = self.core.embed_device_many(image_sets, batch_size=self.batch_size, want_taps=want_taps)
+        Zs = out[0] if want_taps else out
         self._zshape = tuple(Zs[0].shape[1:])
+        if want_taps:
+            self._tapshapes = [(tuple(t.shape[1:]), t.dtype) for t in out[1][0]]
+            return Zs, [Taps(feats, int(z.shape[0])) for feats, z in zip(out[1], Zs)]
         return Zs
+
+    def taps_to_packed(self, taps):
+        """A received block of taps -> its packed embeddings (aggregate + pack: the sender's own Z, bit for bit)."""
+        if taps.n == 0:
+            return self.pack(self._empty(False))
+        return self.pack(self.core.aggregate_taps(taps.feats))
 
     # ---- packed blocks and the pair kernels (see acnative for the semantics)
     def pack(self, Z):
@@ -261,13 +313,17 @@ class _Ring:
     Under a host backend (gloo: the CPU tests, and the tests that run several ranks on ONE GPU, which RCCL
     refuses) device tensors are staged through host memory."""
 
-    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES, post=True):
+    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES, post=True, decode=None):
+        """local: the rank's own block as it travels - a packed block, or its Taps with decode = ops.taps_to_packed
+        (get() then hands out the packed block the consumer wants)."""
         self.ops, self.local, self.sizes, self.rank, self.world, self.group = ops, local, sizes, rank, world, group
+        self.decode = decode
         self.cap = max(sizes) if sizes else 0
         self.last = last_step
-        # bytes of one receive buffer from the SHAPE (hl32 row + its norm), not from the local tensors: a rank with an
-        # empty shard must arrive at the same depth as the others
-        per_buffer = max(1, (local.D * 4 + 4) * local.P * self.cap)
+        # bytes of one receive buffer from the SHAPE (hl32 row + its norm; or the tap maps), not from the local tensors:
+        # a rank with an empty shard must arrive at the same depth as the others
+        per_image = local.bytes_per_image() if hasattr(local, "bytes_per_image") else (local.D * 4 + 4) * local.P
+        per_buffer = max(1, per_image * self.cap)
         self.depth = max(2, min(max(last_step, 1), remote_bytes // per_buffer))
         self.bufs = [None] * self.depth
         self.pending = {}
@@ -317,7 +373,8 @@ class _Ring:
             n_src = self.sizes[src]
             slot = k % self.depth
             if self.bufs[slot] is None and n_src:
-                self.bufs[slot] = self.ops.empty_packed(self.cap, self.local)
+                self.bufs[slot] = (self.local.empty_like(self.cap) if hasattr(self.local, "empty_like")
+                                   else self.ops.empty_packed(self.cap, self.local))
             recv = self.bufs[slot].slice(0, n_src) if n_src else None
             send_t = self.local.tensors() if self.local.n else []          # an empty shard is neither sent nor received
             recv_t = recv.tensors() if n_src else []
@@ -347,6 +404,8 @@ class _Ring:
         if host_recv is not None:
             for d, h in zip(recv.tensors() if recv is not None else [], host_recv):
                 d.copy_(h)
+        if recv is not None and self.decode is not None:
+            recv = self.decode(recv)          # new tensors: the receive buffer itself is free again once this is queued
         self.prefetch(k - 1 + self.depth)
         return recv
 
@@ -369,8 +428,10 @@ class _UnsupJob:
     accumulator for all categories, so that each costs one collective instead of one per category)."""
 
     def __init__(self, ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
-                 m_out=None, acc=None):
+                 m_out=None, acc=None, send=None):
+        """send: the Taps of the local shard - what travels instead of pk_loc when the seam can re-aggregate them."""
         self.ops, self.pk, self.bounds, self.rank, self.world, self.group, self.device = ops, pk_loc, bounds, rank, world, group, device
+        self.send = send
         self.n = bounds[-1][1]
         self.lo, self.hi = bounds[rank]
         self.P = pk_loc.P
@@ -391,8 +452,9 @@ class _UnsupJob:
             self.by_step.setdefault(item[1], []).append(item)
 
     def post(self):
-        self.ring = _Ring(self.ops, self.pk, self.counts, self.rank, self.world, self.group, last_step=self.last_step,
-                          remote_bytes=self.remote_bytes)
+        self.ring = _Ring(self.ops, self.send if self.send is not None else self.pk, self.counts, self.rank, self.world,
+                          self.group, last_step=self.last_step, remote_bytes=self.remote_bytes,
+                          decode=self.ops.taps_to_packed if self.send is not None else None)
 
     def run(self, step):
         ops, P, acc, shift, lo = self.ops, self.P, self.acc, self.shift, self.lo
@@ -423,7 +485,7 @@ class _UnsupJob:
 
 
 def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto",
-                               remote_bytes=REMOTE_BYTES):
+                               remote_bytes=REMOTE_BYTES, send=None):
     """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard)."""
     n = bounds[-1][1]
     lo, hi = bounds[rank]
@@ -445,7 +507,7 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
         ops.pair_accumulate(minbuf[:, lo * P: hi * P], P, MEAN, lo, shift, acc)
         return ops.pair_finalize(acc, P, MEAN, n - 1, shift)
 
-    job = _UnsupJob(ops, pk_loc, bounds, rank, world, group, device, budget, remote_bytes)
+    job = _UnsupJob(ops, pk_loc, bounds, rank, world, group, device, budget, remote_bytes, send=send)
     if world > 1:
         dist.all_reduce(job.m, op=dist.ReduceOp.MAX, group=group)
     job.prepare()
@@ -464,8 +526,10 @@ class _SupJob:
     host read) -> fix() when it is set (collective: every rank or none) -> finish."""
 
     def __init__(self, ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
-                 remote_bytes=REMOTE_BYTES, m_out=None, overflow=None):
+                 remote_bytes=REMOTE_BYTES, m_out=None, overflow=None, send=None):
+        """send: the Taps of the local BANK shard (travels instead of pk_bank_loc, see _UnsupJob)."""
         self.ops, self.pk, self.bank, self.rank, self.world, self.group, self.device = ops, pk_loc, pk_bank_loc, rank, world, group, device
+        self.send = send
         self.P, self.n_loc = pk_loc.P, pk_loc.n
         self.counts = [b - a for a, b in bank_bounds]
         self.budget, self.remote_bytes = budget, remote_bytes
@@ -485,8 +549,9 @@ class _SupJob:
         self.q16 = ops.h16(self.pk)
 
     def _new_ring(self):
-        return _Ring(self.ops, self.bank, self.counts, self.rank, self.world, self.group, last_step=self.last_step,
-                     remote_bytes=self.remote_bytes)
+        return _Ring(self.ops, self.send if self.send is not None else self.bank, self.counts, self.rank, self.world,
+                     self.group, last_step=self.last_step, remote_bytes=self.remote_bytes,
+                     decode=self.ops.taps_to_packed if self.send is not None else None)
 
     def post(self):
         self.ring = self._new_ring()
@@ -518,7 +583,7 @@ def _can_prune(ops, pk_loc, prune):
 
 
 def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
-                             remote_bytes=REMOTE_BYTES, prune=True):
+                             remote_bytes=REMOTE_BYTES, prune=True, send=None):
     """w fp32 [n_loc, P]: min over every bank image (utils.py:230-237 for every i of the shard).  The bank
     shards go round the ring.  Default: the pruned EXACT nearest-neighbour search - per shard one MFMA launch on
     the fp16 high halves keeps, for every query patch, the bank patches within a proven error bound of the
@@ -531,7 +596,7 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     counts = [b - a for a, b in bank_bounds]
     m = sum(counts)
     if _can_prune(ops, pk_loc, prune):
-        job = _SupJob(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget, remote_bytes)
+        job = _SupJob(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget, remote_bytes, send=send)
         if world > 1:
             dist.all_reduce(job.mk, op=dist.ReduceOp.MAX, group=group)
             dist.all_reduce(job.mq, op=dist.ReduceOp.MAX, group=group)
@@ -550,7 +615,8 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
             job.fix()
         return job.finish()
     acc = ops.new_acc(n_loc * P, MIN, device)
-    ring = _Ring(ops, pk_bank_loc, counts, rank, world, group, last_step=world - 1, remote_bytes=remote_bytes)
+    ring = _Ring(ops, send if send is not None else pk_bank_loc, counts, rank, world, group, last_step=world - 1,
+                 remote_bytes=remote_bytes, decode=ops.taps_to_packed if send is not None else None)
     c = block_images(P, budget)
     for k in range(world):
         keys = pk_bank_loc if k == 0 else ring.get(k)
@@ -631,9 +697,16 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     counts = [b - a for a, b in bounds]
     mark = _marker(ops, timings)
 
+    # several ranks: the ring carries the tapped feature maps (4.8 MB per image) instead of packed embeddings (12.85 MB)
+    # whenever the seam can turn received taps into packed blocks; the unsupervised "slices" schedule gathers packed Z
+    use_taps = world > 1 and getattr(ops, "ring_payload", None) == "taps" and not (supervised == "unsupervised" and schedule == "slices")
+    taps_loc = None
     t0 = time.perf_counter()
     if Z_loc is None:
-        Z_loc = ops.embed(images[lo:hi])                               # [n_loc, P, D]
+        if use_taps and supervised == "unsupervised":
+            Z_loc, taps_loc = ops.embed(images[lo:hi], want_taps=True)
+        else:
+            Z_loc = ops.embed(images[lo:hi])                           # [n_loc, P, D]
     elif Z_loc.shape[0] != hi - lo:
         raise ValueError("Z_loc holds %d images, this rank's shard has %d" % (Z_loc.shape[0], hi - lo))
     mark("embed", t0)
@@ -646,13 +719,18 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         sel = select_bank(train_images.shape[0], n, train_ratio, bank_seed)
         bb = shard_bounds(len(sel), world)
         blo, bhi = bb[rank]
-        bank_loc = ops.embed(train_images[sel[blo:bhi]])
+        bank_taps = None
+        if use_taps:
+            bank_loc, bank_taps = ops.embed(train_images[sel[blo:bhi]], want_taps=True)
+        else:
+            bank_loc = ops.embed(train_images[sel[blo:bhi]])
         w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget,
-                                         remote_bytes, prune)
-        del bank_loc
+                                         remote_bytes, prune, send=bank_taps)
+        del bank_loc, bank_taps
     elif supervised == "unsupervised":
         w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule,
-                                           remote_bytes)
+                                           remote_bytes, send=taps_loc)
+        taps_loc = None
     else:                                                              # "average" (main.py:290-291)
         w_loc = None
     mark("pair_min_dist", t0)
@@ -690,9 +768,13 @@ def category_cost(n, m=None, t_img=0.46e-3, t_pair=6.2e-6):
     return (n + m) * t_img + n * m * t_pair * 0.72
 
 
-def _embed_sets(ops, sets):
+def _embed_sets(ops, sets, want_taps=False):
+    """[Z per set] (+ [Taps per set] when want_taps): one stream of ViT batches when the seam has embed_many."""
     if hasattr(ops, "embed_many"):
-        return ops.embed_many(sets)
+        return ops.embed_many(sets, want_taps=True) if want_taps else ops.embed_many(sets)
+    if want_taps:
+        pairs = [ops.embed(s, want_taps=True) for s in sets]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
     return [ops.embed(s) for s in sets]
 
 
@@ -792,10 +874,23 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
             for c in grp:
                 blo, bhi = bank_bounds[c][rank]
                 sets.append(items[c]["train_images"][sels[c][blo:bhi]])
-        Zs = _embed_sets(ops, sets) if sets else []
+        # several ranks: the rings carry the tapped feature maps of the shards (see run_category)
+        use_taps = world > 1 and getattr(ops, "ring_payload", None) == "taps" and supervised in ("unsupervised", "supervised")
+        taps = None
+        if use_taps and sets:
+            Zs, taps = _embed_sets(ops, sets, want_taps=True)
+        else:
+            Zs = _embed_sets(ops, sets) if sets else []
         Z = {c: (Zs[i] if Z_locs is None else Z_locs[c]) for i, c in enumerate(grp)}
         Zb = {c: Zs[ntest + i] for i, c in enumerate(grp)} if supervised == "supervised" else {}
-        del Zs
+        # what each category's ring sends: unsupervised - the taps of its test shard; supervised - of its bank shard
+        send = {c: None for c in grp}
+        if taps is not None:
+            if supervised == "supervised":
+                send = {c: taps[ntest + i] for i, c in enumerate(grp)}
+            elif Z_locs is None:
+                send = {c: taps[i] for i, c in enumerate(grp)}
+        del Zs, taps
         mark("embed", t0)
         device = Z[grp[0]].device
 
@@ -812,16 +907,17 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
             if sup and not _can_prune(ops, pk[grp[0]], prune):
                 for c in grp:          # exhaustive blocks: no phases to interleave
                     w[c] = alpha_weights_supervised(ops, pk[c], pkb[c], bank_bounds[c], rank, world, group, device, budget,
-                                                    remote_bytes, prune)
+                                                    remote_bytes, prune, send=send[c])
             else:
                 # the rings of the group must ALL be fully posted (depth = every step); a group whose receive buffers
                 # exceed the budget falls back to the category-by-category order (each ring double-buffers on its own)
                 steps = (world - 1) if sup else world // 2
-                ring_total = sum(steps * (pk[c].D * 4 + 4) * P * max((b - a) for a, b in (bank_bounds[c] if sup else all_bounds[c]))
-                                 for c in grp)
-                together = world > 1 and ring_total <= ring_bytes_all and all(
-                    steps * (pk[c].D * 4 + 4) * P * max((b - a) for a, b in (bank_bounds[c] if sup else all_bounds[c])) <= remote_bytes
-                    for c in grp)
+
+                def ring_bytes(c):          # receive buffers of category c's ring with every step posted
+                    per_image = send[c].bytes_per_image() if send[c] is not None else (pk[c].D * 4 + 4) * P
+                    return steps * per_image * max((b - a) for a, b in (bank_bounds[c] if sup else all_bounds[c]))
+                together = world > 1 and sum(ring_bytes(c) for c in grp) <= ring_bytes_all and all(
+                    ring_bytes(c) <= remote_bytes for c in grp)
                 m_all = ops.new_acc(len(grp), MEAN, device).view(torch.float32)       # 2 fp32 maxima per category, zeros
                 jobs = {}
                 if sup:
@@ -829,13 +925,14 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
                     flags32 = flags.view(torch.int32)[: len(grp)]
                     for i, c in enumerate(grp):
                         jobs[c] = _SupJob(ops, pk[c], pkb[c], bank_bounds[c], rank, world, group, device, budget, remote_bytes,
-                                          m_out=m_all[2 * i: 2 * i + 2], overflow=flags32[i: i + 1])
+                                          m_out=m_all[2 * i: 2 * i + 2], overflow=flags32[i: i + 1], send=send[c])
                 else:
                     acc_all = ops.new_acc(sum(ns[c] for c in grp) * P, MEAN, device)
                     off = 0
                     for i, c in enumerate(grp):
                         jobs[c] = _UnsupJob(ops, pk[c], all_bounds[c], rank, world, group, device, budget, remote_bytes,
-                                            m_out=m_all[2 * i: 2 * i + 1], acc=acc_all[off * P: (off + ns[c]) * P])
+                                            m_out=m_all[2 * i: 2 * i + 1], acc=acc_all[off * P: (off + ns[c]) * P],
+                                            send=send[c])
                         off += ns[c]
                 if world > 1:
                     dist.all_reduce(m_all, op=dist.ReduceOp.MAX, group=group)

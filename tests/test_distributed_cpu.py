@@ -373,3 +373,80 @@ def test_categories_as_one_job_equal_the_per_category_loop(world, mode, schedule
             for c, r in enumerate(ref):
                 for tv, res in r["by_tau"].items():
                     np.testing.assert_array_equal(np.load(os.path.join(d, "pdist_%d_%s.npy" % (c, tv))), res["pdist"].numpy())
+
+
+# ------------------------------------------------------------------ the ring carries taps instead of packed embeddings
+class ToyTapsOps(ToyOps):
+    """ToyOps whose ring payload is the "tapped feature maps" (here: the flattened pixels the toy embedding reads):
+    embed(..., want_taps=True) hands them out and taps_to_packed re-embeds + packs a received block - the seam of
+    HipOps.taps_to_packed (aggregate + pack), so the taps ring, its receive buffers and its decode step run under gloo."""
+    ring_payload = "taps"
+
+    def embed(self, images, want_taps=False):
+        from patchcore.pipeline import Taps
+        Z = ToyOps.embed(self, images)
+        if not want_taps:
+            return Z
+        n = images.shape[0]
+        flat = images.reshape(n, -1)[:, : self.P * self.D].contiguous() if n else torch.zeros(0, self.P * self.D)
+        return Z, Taps([flat], n)
+
+    def taps_to_packed(self, taps):
+        f = taps.feats[0].reshape(taps.n, self.P, self.D)
+        return self.pack((f * 1.5 + f.roll(1, dims=2) * 0.5).contiguous())
+
+
+class ToyTapsPrunedOps(ToyTapsOps, ToyPrunedOps):
+    pass
+
+
+def _worker_taps(rank, world, init_file, out_dir, mode, many, kw):
+    sys.path[:0] = [ROOT, MODELS]
+    from patchcore.pipeline import run_category, run_categories
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    ops = ToyTapsPrunedOps(0, None) if mode == "supervised_pruned" else ToyTapsOps()
+    m = "supervised" if mode.startswith("supervised") else mode
+    if many:
+        outs = run_categories(ops, _category_items(), m, tau=1.0, train_ratio=1.0, **kw)
+    else:
+        images, train = _inputs()
+        outs = [run_category(ops, images, m, tau=1.0, train_images=train, train_ratio=1.0, **kw)]
+    for c, o in enumerate(outs):
+        np.save(os.path.join(out_dir, "alpha_%d_%d.npy" % (rank, c)), o["alpha"].numpy())
+        np.save(os.path.join(out_dir, "X_%d_%d.npy" % (rank, c)), o["X"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,many,kw", [
+    (2, "unsupervised", False, {}),
+    (4, "unsupervised", False, {"budget": 2 * 2 * 12 * 4}),
+    (3, "supervised", False, {}),
+    (4, "supervised", False, {"remote_bytes": 1}),            # double-buffered ring: a receive buffer is decoded, then refilled
+    (3, "supervised_pruned", False, {}),
+    (3, "unsupervised", True, {}),
+    (4, "supervised_pruned", True, {}),
+])
+def test_ring_of_taps_equals_ring_of_packed_shards(world, mode, many, kw):
+    """Several ranks send the tapped feature maps round the ring (2.7x fewer bytes on the real shapes) and the receiver
+    re-aggregates + packs them; the result is the one-rank result of the plain seam, bit for bit (the pruned toy search
+    takes its minimum in another order of operations: 1e-6)."""
+    from patchcore.pipeline import run_category
+    m = "supervised" if mode.startswith("supervised") else mode
+    if many:
+        sets = [(it["images"], it["train_images"]) for it in _category_items()]
+    else:
+        sets = [_inputs()]
+    ref = [run_category(ToyOps(), a, m, tau=1.0, train_images=b, train_ratio=1.0) for a, b in sets]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_taps, args=(world, os.path.join(d, "rdzv"), d, mode, many, kw), nprocs=world, join=True)
+        for rk in range(world):
+            for c, r in enumerate(ref):
+                a = np.load(os.path.join(d, "alpha_%d_%d.npy" % (rk, c)))
+                X = np.load(os.path.join(d, "X_%d_%d.npy" % (rk, c)))
+                if mode == "supervised_pruned":
+                    np.testing.assert_allclose(a, r["alpha"].numpy(), rtol=1e-6)
+                    np.testing.assert_allclose(X, r["X"], rtol=1e-5, atol=1e-6)
+                else:
+                    np.testing.assert_array_equal(a, r["alpha"].numpy())
+                    np.testing.assert_array_equal(X, r["X"])

@@ -68,9 +68,10 @@ def test_two_ranks_on_one_gpu_match_one_rank(dev, mode):
         for r in range(2):
             a = np.load(os.path.join(d, "alpha_%d.npy" % r))
             X = np.load(os.path.join(d, "X_%d.npy" % r))
-            # batches of different size take different tile paths in the ViT GEMMs: fp32-level, not bitwise
-            np.testing.assert_allclose(a, ref["alpha"].cpu().numpy(), rtol=2e-4, atol=1e-8)
-            np.testing.assert_allclose(X, ref["X"], rtol=0, atol=2e-5)
+            # the ring carries the ViT taps here (HipOps with a backbone): the receiver re-aggregates and packs them.
+            # A ViT batch of another size gives every image the same bits (the GEMM kernels accumulate each output
+            # row in one fixed K order), so two ranks equal one rank exactly
+            assert np.array_equal(a, ref["alpha"].cpu().numpy()) and np.array_equal(X, ref["X"])
 
 
 def _worker_small(rank, world, init_file, out_dir):
