@@ -166,6 +166,9 @@ struct EpiPairMin {
   template <class F>
   __device__ bool fast(F& f, int m_wave, int n_wave, int lane, bool both_ways) const {
     static_assert(F::TW == 16 && F::NT == 4 && F::NR == 4, "written for the 16x16x32 accumulator layout");
+#ifdef AC_NO_FAST_EPI                        // diagnostic builds: the general epilogue everywhere (same-box A/B)
+    return false;
+#endif
     if (m_wave + 64 > M || n_wave + 64 > N || P < 64 || (reinterpret_cast<uintptr_t>(key_sq) & 15)) return false;
     const int g = lane >> 4, c = lane & 15;
     f32x4 ks[4];

@@ -24,16 +24,16 @@ constexpr int FLUSH_STAGES = 16;          // two-level sum: MFMA accumulator flu
 // grouped order so that tiles sharing A/B panels share an L2.
 // Blocks are dealt round-robin to the 8 XCDs (block id & 7 names the XCD, id >> 3 its slot there): position of
 // block `id` in the linear tile order.
-//   AC_XCD_WINDOW == 0: every XCD walks ONE contiguous eighth of the order (the 8 XCDs work on 8 far-apart regions;
-//     rounds 1-3).
-//   AC_XCD_WINDOW == W (default 32 = the workgroups one XCD runs at a time): windows of W consecutive tiles are dealt
-//     to the XCDs in turn, so at any time the 8 XCDs work on 8 NEIGHBOURING windows (the same group of tile rows,
-//     adjacent columns): what one XCD misses in its L2 the Infinity Cache already holds for another.  The tail
-//     (total % 8W tiles) keeps the identity order.  Same-box A/B (profiles/r04_allpairs_xcd_window_and_fixup_cost_ab.txt):
-//     all-pairs -0.9 % at N = 83, -1.7 % at N = 167 with W = 32; W = 16 equal, W = 64 / 128 +2 % (slower); the ViT
-//     linear layers do not move.  Results are bit-identical (only the order of the tiles changes).
+//   AC_XCD_WINDOW == 0 (default): every XCD walks ONE contiguous eighth of the order, so the 32 workgroups an XCD runs
+//     at a time are 32 consecutive tiles and consecutive rounds stay on the same row panels.
+//   AC_XCD_WINDOW == W (diagnostic builds): windows of W consecutive tiles are dealt to the XCDs in turn, so at any time
+//     the 8 XCDs work on 8 NEIGHBOURING windows (what one XCD misses in its L2 the Infinity Cache may already hold for
+//     another).  Measured on the all-pairs kernel, round 4 (profiles/r04_allpairs_xcd_window_and_fixup_cost_ab.txt,
+//     r04_allpairs_xcd_window_pmc.txt): the L2 hit rate FALLS from 77 % to 55 % and the fabric traffic doubles (94 ->
+//     181 GB per launch); with the round-3 epilogue W = 32 was 0.2-0.9 % faster, with the register-only epilogue it is
+//     0.6-1.5 % SLOWER (two boxes, interleaved rounds, N = 83 and 167); W = 16 / 64 / 128 lose in both.  Not shipped.
 #ifndef AC_XCD_WINDOW
-#define AC_XCD_WINDOW 32
+#define AC_XCD_WINDOW 0
 #endif
 __device__ inline int xcd_lin(int id, long long total) {
   const int xcd = id & 7, slot = id >> 3;

@@ -35,14 +35,19 @@ P, D = 784, 4096
 
 
 class LocalRing:
-    """Stands in for pipeline._Ring: the shard of rank + k is a slice of a local packed copy of the whole category."""
+    """Stands in for pipeline._Ring: the shard of rank + k is a slice of a local copy of the whole category - of its
+    TAPS (what the ring carries since round 4), which get() turns into a packed block exactly as the real ring does
+    (aggregate + pack: part of the measured compute), or of its packed embeddings (--payload packed)."""
 
-    def __init__(self, pk_all, bounds):
-        self.pk_all, self.bounds = pk_all, bounds
+    def __init__(self, ops, src, bounds, taps):
+        self.ops, self.src, self.bounds, self.taps = ops, src, bounds, taps
 
     def get(self, k):
         lo, hi = self.bounds[k % len(self.bounds)]
-        return self.pk_all.slice(lo, hi) if hi > lo else None
+        if hi <= lo:
+            return None
+        blk = self.src.slice(lo, hi)
+        return self.ops.taps_to_packed(blk) if self.taps else blk
 
 
 def main():
@@ -52,6 +57,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--link-gbs", type=float, default=50.0, help="ASSUMED effective one-direction rate of one xGMI link")
     ap.add_argument("--gpus", type=int, nargs="+", default=[1, 2, 4, 8])
+    ap.add_argument("--payload", default="taps", choices=["taps", "packed"], help="what the ring carries")
     a = ap.parse_args()
     import acnative
     import patchcore.backbones
@@ -71,9 +77,14 @@ def main():
     ns = {c: len(labels[c]) for c in cats}
     images = {c: synthetic.make_images(c, labels[c]).to(dev) for c in cats}
     # the whole category packed once: the source of the "received" shards
-    pk_all = {}
+    pk_all, src_all = {}, {}
+    taps_mode = a.payload == "taps"
     for c in cats:
-        pk_all[c] = ops.pack(ops.embed(images[c]))
+        Zc, tc = ops.embed(images[c], want_taps=True)
+        pk_all[c] = ops.pack(Zc)
+        src_all[c] = tc if taps_mode else pk_all[c]
+        del Zc
+    per_image_bytes = src_all[cats[0]].bytes_per_image() if taps_mode else P * (D * 4 + 4)
 
     def timed(fn):
         torch.cuda.synchronize()
@@ -90,7 +101,7 @@ def main():
             job = _UnsupJob(ops, ops.pack(Z[c]), bounds, 0, G, None, dev)
             job.m = ops.max_sq([pk_all[c]], dev)                 # what the MAX all-reduce would deliver
             job.prepare()
-            job.ring = LocalRing(pk_all[c], bounds)
+            job.ring = LocalRing(ops, src_all[c], bounds, taps_mode)
             jobs[c] = job
         return jobs
 
@@ -100,7 +111,7 @@ def main():
             _, a32 = ops.alpha_softmax(w, 1.0, 1)
             ops.weighted_avg(a32, Z[c])
 
-    result = {"assumed_xgmi_link_GBs": a.link_gbs, "categories": cats, "n": [ns[c] for c in cats], "per_G": {}}
+    result = {"ring_payload": a.payload, "ring_bytes_per_image": per_image_bytes, "assumed_xgmi_link_GBs": a.link_gbs, "categories": cats, "n": [ns[c] for c in cats], "per_G": {}}
     per_cat_1gpu = None
     for G in a.gpus:
         shards = {c: images[c][shard_bounds(ns[c], G)[0][0]: shard_bounds(ns[c], G)[0][1]] for c in cats}
@@ -129,7 +140,7 @@ def main():
             job = _UnsupJob(ops, ops.pack(z), bounds, 0, G, None, dev)
             job.m = ops.max_sq([pk_all[c]], dev)
             job.prepare()
-            job.ring = LocalRing(pk_all[c], bounds)
+            job.ring = LocalRing(ops, src_all[c], bounds, taps_mode)
             return job
 
         def run_pipeline():
@@ -154,7 +165,7 @@ def main():
         if G == 1:
             per_cat_1gpu = best_seq[2]
         # ---- ring timeline, est.: category c's `steps` shards travel concurrently (one link each), categories queue
-        shard_mb = [shard_bounds(ns[c], G)[0][1] * P * (D * 4 + 4) / 1e6 for c in cats]
+        shard_mb = [shard_bounds(ns[c], G)[0][1] * per_image_bytes / 1e6 for c in cats]
         ms_per_cat = [mb / (a.link_gbs * 1e3) * 1e3 / 1.0 if G > 1 else 0.0 for mb in shard_mb]   # MB / (GB/s) = ms
         # sequential: each category's transfer starts after its own embed + pack and hides under its own step 0 only;
         # take step 0 of a category = its share of t0s (measured jointly), proportional to n^2
