@@ -24,33 +24,39 @@ constexpr int FLUSH_STAGES = 16;          // two-level sum: MFMA accumulator flu
 // grouped order so that tiles sharing A/B panels share an L2.
 // Blocks are dealt round-robin to the 8 XCDs (block id & 7 names the XCD, id >> 3 its slot there): position of
 // block `id` in the linear tile order.
-//   AC_XCD_WINDOW == 0 (default): every XCD walks ONE contiguous eighth of the order, so the 32 workgroups an XCD runs
-//     at a time are 32 consecutive tiles and consecutive rounds stay on the same row panels.
-//   AC_XCD_WINDOW == W (diagnostic builds): windows of W consecutive tiles are dealt to the XCDs in turn, so at any time
-//     the 8 XCDs work on 8 NEIGHBOURING windows (what one XCD misses in its L2 the Infinity Cache may already hold for
-//     another).  Measured on the all-pairs kernel, round 4 (profiles/r04_allpairs_xcd_window_and_fixup_cost_ab.txt,
-//     r04_allpairs_xcd_window_pmc.txt): the L2 hit rate FALLS from 77 % to 55 % and the fabric traffic doubles (94 ->
-//     181 GB per launch); with the round-3 epilogue W = 32 was 0.2-0.9 % faster, with the register-only epilogue it is
-//     0.6-1.5 % SLOWER (two boxes, interleaved rounds, N = 83 and 167); W = 16 / 64 / 128 lose in both.  Not shipped.
-#ifndef AC_XCD_WINDOW
-#define AC_XCD_WINDOW 0
+//   W == 0: every XCD walks ONE contiguous eighth of the order, so the 32 workgroups an XCD runs at a time are 32
+//     consecutive tiles and consecutive rounds stay on the same row panels.
+//   W > 0: windows of W consecutive tiles are dealt to the XCDs in turn, so at any time the 8 XCDs work on 8 NEIGHBOURING
+//     windows (what one XCD misses in its L2 the Infinity Cache may already hold for another); the tail (total % 8W
+//     tiles) keeps the identity order.
+// Measured on the all-pairs kernel, round 4, interleaved rounds on one box each (profiles/r04_allpairs_xcd_window_*.txt),
+// W = 32 against W = 0, register-only epilogue: the TRIANGLE of a symmetric launch +0.7 % (N = 83), +1.5 % (167), 0 (585)
+// - its L2 hit rate falls from 77 % to 55 % and the fabric traffic doubles, 94 -> 181 GB per launch - but RECTANGLES
+// (two-way blocks: what a rank of a multi-GPU run and the sub-blocks of a large category launch) -3.5 % at 11 x 11 images,
+// -1.0 % at 42 x 42, -0.5 % at 400 x 400, config 5b at N = 2000 -1.6 %; W = 16 / 64 / 128 lose everywhere; the ViT linear
+// layers do not move.  Hence: rectangles W = 32, the triangle W = 0.  Only the ORDER of the tiles changes: bit-identical.
+#ifndef AC_XCD_WINDOW_RECT
+#define AC_XCD_WINDOW_RECT 32
 #endif
+#ifndef AC_XCD_WINDOW_TRI
+#define AC_XCD_WINDOW_TRI 0
+#endif
+template <int W>
 __device__ inline int xcd_lin(int id, long long total) {
   const int xcd = id & 7, slot = id >> 3;
-#if AC_XCD_WINDOW > 0
-  constexpr int W = AC_XCD_WINDOW;
-  const long long full = total / (8 * W) * (8 * W);
-  if (id >= full) return id;
-  return ((slot / W) * 8 + xcd) * W + slot % W;
-#else
-  const int q = (int)(total >> 3), r = (int)(total & 7);
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-#endif
+  if constexpr (W > 0) {
+    const long long full = total / (8 * W) * (8 * W);
+    if (id >= full) return id;
+    return ((slot / W) * 8 + xcd) * W + slot % W;
+  } else {
+    const int q = (int)(total >> 3), r = (int)(total & 7);
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
 }
 
 __device__ inline void raster(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
   int total = tiles_m * tiles_n;
-  int lin = xcd_lin(id, total);
+  int lin = xcd_lin<AC_XCD_WINDOW_RECT>(id, total);
   int per_group = group_m * tiles_n;
   int g = lin / per_group, within = lin - g * per_group;
   int first = g * group_m;

@@ -121,7 +121,7 @@ __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn
 }
 
 __device__ inline int xcd_chunk_lin(int id, long long total) {
-  return gemm::xcd_lin(id, total);
+  return gemm::xcd_lin<AC_XCD_WINDOW_TRI>(id, total);
 }
 
 // Map a linear tile id to (tm, tn).  Symmetric problems: tiles_m / tiles_n are the full tile counts Tm / Tn and

@@ -35,17 +35,29 @@ def main():
     ap.add_argument("--one-way", type=lambda v: [int(x) for x in v.split(",") if x], default=[],
                     help="also time ONE-WAY blocks (all N key images x the first Q query images) on the first library: what "
                          "re-measuring Q/N of the query patches through the accurate kernel would cost")
+    ap.add_argument("--two-way", type=int, default=0,
+                    help="instead of the symmetric launch: a TWO-WAY block, keys = the first n images, queries = this many more")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [(s.split("=", 1)[0], bind(s.split("=", 1)[1])) for s in a.libs]
     g = torch.Generator(device="cpu").manual_seed(3)
-    Z = (torch.randn((a.n, P, D), generator=g) * 0.6).to(dev)
+    nz = a.n + a.two_way
+    Z = torch.empty((nz, P, D), device=dev)
+    for s0 in range(0, nz, 64):                          # generated in slices: N = 1200 is 15 GB
+        Z[s0:s0 + 64] = (torch.randn((min(64, nz - s0), P, D), generator=g) * 0.6).to(dev)
     st = torch.cuda.current_stream().cuda_stream
-    hl = torch.empty((a.n * P, D * 4), dtype=torch.uint8, device=dev)
-    sq = torch.empty((a.n * P,), dtype=torch.float32, device=dev)
-    assert libs[0][1].ac_pack_hl32(Z.data_ptr(), a.n * P, D, D, hl.data_ptr(), sq.data_ptr(), st) == 0
-    mb = torch.empty((a.n, a.n * P), dtype=torch.int32, device=dev)
+    hl = torch.empty((nz * P, D * 4), dtype=torch.uint8, device=dev)
+    sq = torch.empty((nz * P,), dtype=torch.float32, device=dev)
+    assert libs[0][1].ac_pack_hl32(Z.data_ptr(), nz * P, D, D, hl.data_ptr(), sq.data_ptr(), st) == 0
+    del Z
+    if a.two_way:
+        nq = a.two_way
+        mb = torch.empty((a.n, nq * P), dtype=torch.int32, device=dev)
+        mbt = torch.empty((nq, a.n * P), dtype=torch.int32, device=dev)
+        qhl, qsq = hl[a.n * P:], sq[a.n * P:]
+    else:
+        mb = torch.empty((a.n, a.n * P), dtype=torch.int32, device=dev)
     times = {name: [] for name, _ in libs}
     ref = None
     same = {}
@@ -54,8 +66,14 @@ def main():
             assert lib.ac_fill_u32(mb.data_ptr(), mb.numel(), INF, st) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = lib.ac_pair_min_sq_packed(hl.data_ptr(), sq.data_ptr(), a.n, hl.data_ptr(), sq.data_ptr(), a.n, P, D,
-                                           mb.data_ptr(), None, 0, 1, st)
+            if a.two_way:
+                assert lib.ac_fill_u32(mbt.data_ptr(), mbt.numel(), INF, st) == 0
+                e0.record()
+                rc = lib.ac_pair_min_sq_packed(hl.data_ptr(), sq.data_ptr(), a.n, qhl.data_ptr(), qsq.data_ptr(), nq, P, D,
+                                               mb.data_ptr(), mbt.data_ptr(), 0, 1, st)
+            else:
+                rc = lib.ac_pair_min_sq_packed(hl.data_ptr(), sq.data_ptr(), a.n, hl.data_ptr(), sq.data_ptr(), a.n, P, D,
+                                               mb.data_ptr(), None, 0, 1, st)
             e1.record()
             assert rc == 0, lib.ac_last_error()
             torch.cuda.synchronize()
@@ -65,7 +83,7 @@ def main():
                 if ref is None:
                     ref = mb.clone()
                 same[name] = bool(torch.equal(mb, ref))
-    flop = a.n * (a.n - 1.0) * 2 * P * P * D
+    flop = (2.0 * a.n * a.two_way if a.two_way else a.n * (a.n - 1.0)) * 2 * P * P * D
     for name, _ in libs:
         t = times[name]
         print("%-12s median %.3f ms  min %.3f  max %.3f  (%.0f TFLOP/s algorithmic at the median)  bit-equal to %s: %s"
