@@ -42,7 +42,7 @@ import patchcore.sampler  # noqa: E402
 import patchcore.datasets.mvtec as mvtec  # noqa: E402
 import patchcore.datasets.synthetic as synthetic  # noqa: E402
 from patchcore.patchcore import AnomalyClusteringCore  # noqa: E402
-from patchcore.pipeline import HipOps, run_categories, run_category, select_bank, shard_bounds  # noqa: E402
+from patchcore.pipeline import HipOps, category_rot, run_categories, run_category, select_bank, shard_bounds  # noqa: E402
 
 device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu")
 
@@ -102,14 +102,16 @@ def _ranks():
     return (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
 
 
-def _load_test(path, category, dataset, cache, whole=False):
+def _load_test(path, category, dataset, cache, whole=False, rot=0):
     """ONE pass over the test split: decode on the host, resize / crop / normalise on the GPU, and collect the per-image
     records (what test.py reads as `info`: the item dicts minus pixels, collated with batch size 1) on the way.
     The reference walks the test set twice with batch size 1 (main.py:254-262, :266).  `cache` (a dict the caller keeps
     per category): the loaded test set and its embeddings Z are the same for every mode, so `--supervised both`
     decodes and embeds the test images once.  Launched under torchrun, a rank decodes only the files of its own
-    image shard (records of all); whole=True: all of them (a rank that may be given the WHOLE category)."""
+    image shard (records of all); whole=True: all of them (a rank that may be given the WHOLE category).  rot: the
+    shard is that of virtual rank (rank + rot) % world (pipeline.run_categories rotates the shards per category)."""
     rank, world = _ranks()
+    rank = (rank + rot) % world
     if "images" not in cache:
         test_dataset = _dataset(path, category, mvtec.DatasetSplit.TEST, dataset)
         cache["n_test"] = len(test_dataset)
@@ -118,10 +120,11 @@ def _load_test(path, category, dataset, cache, whole=False):
     return cache["images"], cache["info"]
 
 
-def _load_bank(path, category, dataset, n_test, train_ratio, whole=False):
+def _load_bank(path, category, dataset, n_test, train_ratio, whole=False, rot=0):
     """The train images the supervised mode may select (main.py:269-281); under torchrun only this rank's slice of
-    the seeded selection is decoded."""
+    the seeded selection is decoded (rot: see _load_test)."""
     rank, world = _ranks()
+    rank = (rank + rot) % world
     train_ds = _dataset(path, category, mvtec.DatasetSplit.TRAIN, dataset)
     only = None
     if world > 1 and not whole:                     # the bank images this rank embeds: its slice of the seeded selection
@@ -184,17 +187,19 @@ def make_categories_data(path, categories, pretrain_embed_dimension, target_embe
     whole = schedule == "per_gpu"                       # a rank may be handed any WHOLE category
     caches = [{} for _ in categories]
     items = []
-    for category, cache in zip(categories, caches):
+    world = _ranks()[1]
+    rots = [category_rot(c, world) if schedule == "pipeline" else 0 for c in range(len(categories))]
+    for category, cache, rot in zip(categories, caches, rots):
         print("{:-^80}".format(category + ' load'))
-        images, _ = _load_test(path, category, dataset, cache, whole=whole)
+        images, _ = _load_test(path, category, dataset, cache, whole=whole, rot=rot)
         items.append({"images": images, "train_images": None})
     results = {}
     Z_locs = None
     for supervised in modes:
         print("{:-^80}".format("%d categories start %s" % (len(categories), supervised)))
         if supervised == "supervised":
-            for category, cache, it in zip(categories, caches, items):
-                it["train_images"] = _load_bank(path, category, dataset, cache["n_test"], train_ratio, whole=whole)
+            for category, cache, it, rot in zip(categories, caches, items, rots):
+                it["train_images"] = _load_bank(path, category, dataset, cache["n_test"], train_ratio, whole=whole, rot=rot)
         outs = run_categories(ops, items, supervised, tau=tau, k=1, train_ratio=train_ratio, want_pdist=False,
                               schedule=schedule, Z_locs=Z_locs if schedule != "per_gpu" else None)
         if schedule != "per_gpu":

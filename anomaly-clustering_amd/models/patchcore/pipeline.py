@@ -44,8 +44,17 @@ packs its share, and the G bank shards go round the same ring.  The min over all
 (a third of the split-fp16 work) keeps the bank patches within a proven bound of the running minimum, and
 only those are measured exactly (alpha_weights_supervised; csrc/alpha.hip).  No collective at the end.
 
+What travels round the ring (round 4): with a backbone behind the seam, the tapped ViT feature maps of a shard
+(`Taps`, 4.8 MB per image) instead of its packed embeddings (12.85 MB); the receiver re-aggregates and packs them -
+the same kernel on the same bytes, so the sender's own packed rows bit for bit.
+
+Several categories (`run_categories`, round 4; the reference loops over them one at a time, examples/main.py:346-366):
+the rank's shards of ALL categories share full ViT batches, every ring is posted before the alpha work starts, the
+steps that need no remote data run first for all categories, and the per-category collectives merge into one each;
+or whole categories are dealt to ranks ("per_gpu").  Same numbers as the per-category loop, bit for bit.
+
 `ops` is the compute seam: by default the HIP library (acnative + AnomalyClusteringCore); the
-world-size-2 gloo tests substitute a CPU stand-in to exercise the schedules and collectives.
+gloo tests (world 2-5) substitute a CPU stand-in to exercise the schedules and collectives.
 """
 import math
 import os
@@ -266,8 +275,9 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def all_gather_rows(local, counts, group=None):
-    """Concatenate per-rank row blocks of unequal length (counts[r] rows on rank r) on every rank.
+def all_gather_rows(local, counts, group=None, rot=0):
+    """Concatenate per-rank row blocks of unequal length (counts[v] rows on the rank whose VIRTUAL rank is v = (rank +
+    rot) % world: see run_category's `rot`) on every rank, in virtual-rank (= image) order.
     Pads to the largest block so one all_gather_into_tensor (one RCCL all-gather) moves everything.  With
     shard_bounds' layout (every non-empty shard but the last is full) the first sum(counts) rows of the
     receive buffer ARE the concatenation - no second copy.  len(counts) == 1: a run on one rank (or a rank
@@ -289,9 +299,10 @@ def all_gather_rows(local, counts, group=None):
     full = 0
     while full < world and counts[full] == cap:
         full += 1
-    if all(c == 0 for c in counts[full + 1:]):       # [cap]*full + [short] + [0]*rest: already contiguous
+    if rot % world == 0 and all(c == 0 for c in counts[full + 1:]):   # [cap]*full + [short] + [0]*rest: already contiguous
         return recv[:total]
-    return torch.cat([recv[r * cap: r * cap + counts[r]] for r in range(world)], dim=0)
+    # block v of the result sits in the receive slot of the REAL rank (v - rot) % world
+    return torch.cat([recv[((v - rot) % world) * cap: ((v - rot) % world) * cap + counts[v]] for v in range(world)], dim=0)
 
 
 def select_bank(n_train, n_test, train_ratio, seed=0):
@@ -313,10 +324,13 @@ class _Ring:
     Under a host backend (gloo: the CPU tests, and the tests that run several ranks on ONE GPU, which RCCL
     refuses) device tensors are staged through host memory."""
 
-    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES, post=True, decode=None):
+    def __init__(self, ops, local, sizes, rank, world, group, last_step, remote_bytes=REMOTE_BYTES, post=True, decode=None,
+                 rot=0):
         """local: the rank's own block as it travels - a packed block, or its Taps with decode = ops.taps_to_packed
-        (get() then hands out the packed block the consumer wants)."""
+        (get() then hands out the packed block the consumer wants).  rank / sizes are in VIRTUAL rank space (run_category's
+        `rot`): the process behind virtual rank v is group rank (v - rot) % world."""
         self.ops, self.local, self.sizes, self.rank, self.world, self.group = ops, local, sizes, rank, world, group
+        self.rot = rot
         self.decode = decode
         self.cap = max(sizes) if sizes else 0
         self.last = last_step
@@ -357,7 +371,8 @@ class _Ring:
             for k in range(1, min(self.depth, last_step) + 1):
                 self.prefetch(k)
 
-    def _peer(self, r):
+    def _peer(self, v):
+        r = (v - self.rot) % self.world
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def prefetch(self, k):
@@ -428,10 +443,11 @@ class _UnsupJob:
     accumulator for all categories, so that each costs one collective instead of one per category)."""
 
     def __init__(self, ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
-                 m_out=None, acc=None, send=None):
-        """send: the Taps of the local shard - what travels instead of pk_loc when the seam can re-aggregate them."""
+                 m_out=None, acc=None, send=None, rot=0):
+        """send: the Taps of the local shard - what travels instead of pk_loc when the seam can re-aggregate them.
+        rank is the VIRTUAL rank (run_category's `rot`)."""
         self.ops, self.pk, self.bounds, self.rank, self.world, self.group, self.device = ops, pk_loc, bounds, rank, world, group, device
-        self.send = send
+        self.send, self.rot = send, rot
         self.n = bounds[-1][1]
         self.lo, self.hi = bounds[rank]
         self.P = pk_loc.P
@@ -454,7 +470,7 @@ class _UnsupJob:
     def post(self):
         self.ring = _Ring(self.ops, self.send if self.send is not None else self.pk, self.counts, self.rank, self.world,
                           self.group, last_step=self.last_step, remote_bytes=self.remote_bytes,
-                          decode=self.ops.taps_to_packed if self.send is not None else None)
+                          decode=self.ops.taps_to_packed if self.send is not None else None, rot=self.rot)
 
     def run(self, step):
         ops, P, acc, shift, lo = self.ops, self.P, self.acc, self.shift, self.lo
@@ -485,7 +501,7 @@ class _UnsupJob:
 
 
 def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, budget=MINBUF_BYTES, schedule="auto",
-                               remote_bytes=REMOTE_BYTES, send=None):
+                               remote_bytes=REMOTE_BYTES, send=None, rot=0):
     """w fp32 [n_loc, P] of the rank's images (utils.py:222-227 for every i of the shard)."""
     n = bounds[-1][1]
     lo, hi = bounds[rank]
@@ -495,8 +511,8 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
         schedule = "ring"
     if schedule == "slices":
         rows = [c * P for c in counts]
-        hl = all_gather_rows(pk_loc.hl, rows, group)
-        sq = all_gather_rows(pk_loc.sq, rows, group)
+        hl = all_gather_rows(pk_loc.hl, rows, group, rot)
+        sq = all_gather_rows(pk_loc.sq, rows, group, rot)
         pk_all = type(pk_loc)(hl, sq, n, P, pk_loc.D)
         shift = ops.fixed_shift(ops.max_sq([pk_all], device), n)
         minbuf = ops.pair_block(pk_all, pk_all, part=rank, nparts=world)          # [N, N*P], +inf outside the slice
@@ -507,7 +523,7 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
         ops.pair_accumulate(minbuf[:, lo * P: hi * P], P, MEAN, lo, shift, acc)
         return ops.pair_finalize(acc, P, MEAN, n - 1, shift)
 
-    job = _UnsupJob(ops, pk_loc, bounds, rank, world, group, device, budget, remote_bytes, send=send)
+    job = _UnsupJob(ops, pk_loc, bounds, rank, world, group, device, budget, remote_bytes, send=send, rot=rot)
     if world > 1:
         dist.all_reduce(job.m, op=dist.ReduceOp.MAX, group=group)
     job.prepare()
@@ -526,10 +542,10 @@ class _SupJob:
     host read) -> fix() when it is set (collective: every rank or none) -> finish."""
 
     def __init__(self, ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
-                 remote_bytes=REMOTE_BYTES, m_out=None, overflow=None, send=None):
-        """send: the Taps of the local BANK shard (travels instead of pk_bank_loc, see _UnsupJob)."""
+                 remote_bytes=REMOTE_BYTES, m_out=None, overflow=None, send=None, rot=0):
+        """send: the Taps of the local BANK shard (travels instead of pk_bank_loc, see _UnsupJob); rank: VIRTUAL rank."""
         self.ops, self.pk, self.bank, self.rank, self.world, self.group, self.device = ops, pk_loc, pk_bank_loc, rank, world, group, device
-        self.send = send
+        self.send, self.rot = send, rot
         self.P, self.n_loc = pk_loc.P, pk_loc.n
         self.counts = [b - a for a, b in bank_bounds]
         self.budget, self.remote_bytes = budget, remote_bytes
@@ -551,7 +567,7 @@ class _SupJob:
     def _new_ring(self):
         return _Ring(self.ops, self.send if self.send is not None else self.bank, self.counts, self.rank, self.world,
                      self.group, last_step=self.last_step, remote_bytes=self.remote_bytes,
-                     decode=self.ops.taps_to_packed if self.send is not None else None)
+                     decode=self.ops.taps_to_packed if self.send is not None else None, rot=self.rot)
 
     def post(self):
         self.ring = self._new_ring()
@@ -583,7 +599,7 @@ def _can_prune(ops, pk_loc, prune):
 
 
 def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget=MINBUF_BYTES,
-                             remote_bytes=REMOTE_BYTES, prune=True, send=None):
+                             remote_bytes=REMOTE_BYTES, prune=True, send=None, rot=0):
     """w fp32 [n_loc, P]: min over every bank image (utils.py:230-237 for every i of the shard).  The bank
     shards go round the ring.  Default: the pruned EXACT nearest-neighbour search - per shard one MFMA launch on
     the fp16 high halves keeps, for every query patch, the bank patches within a proven error bound of the
@@ -596,7 +612,7 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     counts = [b - a for a, b in bank_bounds]
     m = sum(counts)
     if _can_prune(ops, pk_loc, prune):
-        job = _SupJob(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget, remote_bytes, send=send)
+        job = _SupJob(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world, group, device, budget, remote_bytes, send=send, rot=rot)
         if world > 1:
             dist.all_reduce(job.mk, op=dist.ReduceOp.MAX, group=group)
             dist.all_reduce(job.mq, op=dist.ReduceOp.MAX, group=group)
@@ -616,7 +632,7 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
         return job.finish()
     acc = ops.new_acc(n_loc * P, MIN, device)
     ring = _Ring(ops, send if send is not None else pk_bank_loc, counts, rank, world, group, last_step=world - 1,
-                 remote_bytes=remote_bytes, decode=ops.taps_to_packed if send is not None else None)
+                 remote_bytes=remote_bytes, decode=ops.taps_to_packed if send is not None else None, rot=rot)
     c = block_images(P, budget)
     for k in range(world):
         keys = pk_bank_loc if k == 0 else ring.get(k)
@@ -642,7 +658,7 @@ def _alpha_pair(ops, w_loc, Z_loc, tau, k):
     return res, res.float().contiguous()
 
 
-def _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host, mark):
+def _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host, mark, rot=0):
     """alpha = softmax(w / tau), X = alpha . Z, the all-gathers north_star names, pdist on rank 0 - per tau.
     w does not depend on tau (and Z not on the mode): a tau sweep - the reference re-runs everything per tau
     (examples/main.py:346-366, README "tau_list") - only repeats this cheap tail."""
@@ -652,8 +668,8 @@ def _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host,
         t0 = time.perf_counter()
         _, alpha_f32 = _alpha_pair(ops, w_loc, Z_loc, tv, k)
         X_loc = ops.weighted_avg(alpha_f32, Z_loc)
-        X = all_gather_rows(X_loc, counts, group)
-        alpha = all_gather_rows(alpha_f32, counts, group).unsqueeze(1)
+        X = all_gather_rows(X_loc, counts, group, rot)
+        alpha = all_gather_rows(alpha_f32, counts, group, rot).unsqueeze(1)
         mark("alpha_softmax_weighted_avg_gather", t0)
         res = {"alpha": alpha, "X_dev": X}
         t0 = time.perf_counter()
@@ -678,7 +694,7 @@ def _marker(ops, timings):
 
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
-                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True, solo=False):
+                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True, solo=False, rot=0):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
@@ -689,8 +705,14 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     the mode, so a run over several modes embeds the test set once (the reference re-embeds per mode and per tau,
     examples/main.py:346-366).
     solo: work the whole category on THIS rank although a process group exists (no collective at all).
+    rot: the shard this rank holds is that of VIRTUAL rank (rank + rot) % world (every rank passes the same rot).
+    shard_bounds gives the first ranks ceil(N / world) images and the last one the remainder; a job over many categories
+    rotates who is "last" (run_categories) so that no rank holds the large shard of EVERY category.  out["bounds"] is
+    indexed by virtual rank; the gathered alpha / X are in image order whatever rot is.
     Returns dict(alpha fp32 [N, 1, P] on device, X float32 ndarray [N, D], X_dev, pdist (rank 0), bounds)."""
-    rank, world = (0, 1) if solo else _world(group)
+    real_rank, world = (0, 1) if solo else _world(group)
+    rot = rot % world
+    rank = (real_rank + rot) % world                                   # virtual rank: indexes bounds, drives the schedule
     n = images.shape[0]
     bounds = shard_bounds(n, world)
     lo, hi = bounds[rank]
@@ -725,18 +747,19 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         else:
             bank_loc = ops.embed(train_images[sel[blo:bhi]])
         w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget,
-                                         remote_bytes, prune, send=bank_taps)
+                                         remote_bytes, prune, send=bank_taps, rot=rot)
         del bank_loc, bank_taps
     elif supervised == "unsupervised":
         w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule,
-                                           remote_bytes, send=taps_loc)
+                                           remote_bytes, send=taps_loc, rot=rot)
         taps_loc = None
     else:                                                              # "average" (main.py:290-291)
         w_loc = None
     mark("pair_min_dist", t0)
 
-    out = _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host, mark)
+    out = _tail(ops, w_loc, Z_loc, counts, group, real_rank, tau, k, want_pdist, want_host, mark, rot)
     out["bounds"] = bounds
+    out["rot"] = rot
     out["w_loc"] = w_loc
     out["Z_loc"] = Z_loc
     return out
@@ -768,6 +791,14 @@ def category_cost(n, m=None, t_img=0.46e-3, t_pair=6.2e-6):
     return (n + m) * t_img + n * m * t_pair * 0.72
 
 
+def category_rot(c, world):
+    """The rotation run_categories gives category number c ("pipeline" schedule): rank r holds the shard of virtual rank
+    (r + c) % world, so the short last shard of shard_bounds - and the ceil(N / world) ones - move round the ranks from
+    category to category (15 MVTec categories on 8 ranks: 212-219 images per rank instead of 221 on seven ranks and 178
+    on the last; 1 % off the slowest rank, free)."""
+    return c % world if world > 1 else 0
+
+
 def _embed_sets(ops, sets, want_taps=False):
     """[Z per set] (+ [Taps per set] when want_taps): one stream of ViT batches when the seam has embed_many."""
     if hasattr(ops, "embed_many"):
@@ -795,7 +826,7 @@ def _groups(sizes, limit):
 def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ratio=1.0, group=None, bank_seed=0,
                    want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
                    prune=True, schedule="pipeline", group_images=GROUP_IMAGES, ring_bytes_all=RING_BYTES_ALL,
-                   costs=None, solo=False, Z_locs=None):
+                   costs=None, solo=False, Z_locs=None, rotate=True):
     """Several categories as ONE job.  items: [{"images": [N_c, 3, H, W], "train_images": bank candidates or None}].
     Returns [run_category's dict per category]; the numbers are those of the per-category loop the reference runs
     (examples/main.py:346-366) - bit for bit given the same embeddings - only the ORDER of the work changes:
@@ -819,7 +850,9 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
     Categories are taken in groups of at most `group_images` images per rank (Z + packed copy: 25.7 MB per image).
     solo: this rank works ALL of `items` alone although a process group exists (how "per_gpu" runs a rank's share).
     Z_locs: the rank's test-set embeddings of EVERY category from an earlier call (out[c]["Z_loc"]; "pipeline" and
-    "sequential" only): a second mode on the same images embeds only its bank."""
+    "sequential" only): a second mode on the same images embeds only its bank.
+    rotate ("pipeline"): category c is sharded with rotation category_rot(c, world) (see run_category's `rot`): a caller
+    that loads only its own shard of the images must load that of virtual rank (rank + category_rot(c, world)) % world."""
     rank, world = (0, 1) if solo else _world(group)
     mark = _marker(ops, timings)
     ncat = len(items)
@@ -849,6 +882,8 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
 
     ns = [int(it["images"].shape[0]) for it in items]
     all_bounds = [shard_bounds(n, world) for n in ns]
+    rots = [category_rot(c, world) if rotate else 0 for c in range(ncat)]
+    vr = [(rank + rots[c]) % world for c in range(ncat)]               # this rank's virtual rank per category
     sels, bank_bounds = [None] * ncat, [None] * ncat
     if supervised == "supervised":
         for c, it in enumerate(items):
@@ -863,16 +898,16 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
         t0 = time.perf_counter()
         sets = []
         if Z_locs is None:
-            sets = [items[c]["images"][all_bounds[c][rank][0]: all_bounds[c][rank][1]] for c in grp]
+            sets = [items[c]["images"][all_bounds[c][vr[c]][0]: all_bounds[c][vr[c]][1]] for c in grp]
         else:
             for c in grp:
-                if Z_locs[c].shape[0] != all_bounds[c][rank][1] - all_bounds[c][rank][0]:
+                if Z_locs[c].shape[0] != all_bounds[c][vr[c]][1] - all_bounds[c][vr[c]][0]:
                     raise ValueError("Z_locs[%d] holds %d images, this rank's shard has %d"
-                                     % (c, Z_locs[c].shape[0], all_bounds[c][rank][1] - all_bounds[c][rank][0]))
+                                     % (c, Z_locs[c].shape[0], all_bounds[c][vr[c]][1] - all_bounds[c][vr[c]][0]))
         ntest = len(sets)
         if supervised == "supervised":
             for c in grp:
-                blo, bhi = bank_bounds[c][rank]
+                blo, bhi = bank_bounds[c][vr[c]]
                 sets.append(items[c]["train_images"][sels[c][blo:bhi]])
         # several ranks: the rings carry the tapped feature maps of the shards (see run_category)
         use_taps = world > 1 and getattr(ops, "ring_payload", None) == "taps" and supervised in ("unsupervised", "supervised")
@@ -906,8 +941,8 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
                 Zb.clear()
             if sup and not _can_prune(ops, pk[grp[0]], prune):
                 for c in grp:          # exhaustive blocks: no phases to interleave
-                    w[c] = alpha_weights_supervised(ops, pk[c], pkb[c], bank_bounds[c], rank, world, group, device, budget,
-                                                    remote_bytes, prune, send=send[c])
+                    w[c] = alpha_weights_supervised(ops, pk[c], pkb[c], bank_bounds[c], vr[c], world, group, device, budget,
+                                                    remote_bytes, prune, send=send[c], rot=rots[c])
             else:
                 # the rings of the group must ALL be fully posted (depth = every step); a group whose receive buffers
                 # exceed the budget falls back to the category-by-category order (each ring double-buffers on its own)
@@ -924,15 +959,15 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
                     flags = ops.new_acc(len(grp), MEAN, device)                          # int64 zeros; int32 view below
                     flags32 = flags.view(torch.int32)[: len(grp)]
                     for i, c in enumerate(grp):
-                        jobs[c] = _SupJob(ops, pk[c], pkb[c], bank_bounds[c], rank, world, group, device, budget, remote_bytes,
-                                          m_out=m_all[2 * i: 2 * i + 2], overflow=flags32[i: i + 1], send=send[c])
+                        jobs[c] = _SupJob(ops, pk[c], pkb[c], bank_bounds[c], vr[c], world, group, device, budget, remote_bytes,
+                                          m_out=m_all[2 * i: 2 * i + 2], overflow=flags32[i: i + 1], send=send[c], rot=rots[c])
                 else:
                     acc_all = ops.new_acc(sum(ns[c] for c in grp) * P, MEAN, device)
                     off = 0
                     for i, c in enumerate(grp):
-                        jobs[c] = _UnsupJob(ops, pk[c], all_bounds[c], rank, world, group, device, budget, remote_bytes,
+                        jobs[c] = _UnsupJob(ops, pk[c], all_bounds[c], vr[c], world, group, device, budget, remote_bytes,
                                             m_out=m_all[2 * i: 2 * i + 1], acc=acc_all[off * P: (off + ns[c]) * P],
-                                            send=send[c])
+                                            send=send[c], rot=rots[c])
                         off += ns[c]
                 if world > 1:
                     dist.all_reduce(m_all, op=dist.ReduceOp.MAX, group=group)
@@ -970,8 +1005,9 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
         # ---- the cheap tail, per category
         for c in grp:
             counts = [b - a for a, b in all_bounds[c]]
-            out = _tail(ops, w[c], Z[c], counts, group, rank, tau, k, want_pdist, want_host, mark)
+            out = _tail(ops, w[c], Z[c], counts, group, rank, tau, k, want_pdist, want_host, mark, rots[c])
             out["bounds"] = all_bounds[c]
+            out["rot"] = rots[c]
             out["w_loc"] = w[c]
             out["Z_loc"] = Z[c]
             outs[c] = out

@@ -39,11 +39,11 @@ class LocalRing:
     TAPS (what the ring carries since round 4), which get() turns into a packed block exactly as the real ring does
     (aggregate + pack: part of the measured compute), or of its packed embeddings (--payload packed)."""
 
-    def __init__(self, ops, src, bounds, taps):
-        self.ops, self.src, self.bounds, self.taps = ops, src, bounds, taps
+    def __init__(self, ops, src, bounds, taps, rank=0):
+        self.ops, self.src, self.bounds, self.taps, self.rank = ops, src, bounds, taps, rank
 
     def get(self, k):
-        lo, hi = self.bounds[k % len(self.bounds)]
+        lo, hi = self.bounds[(self.rank + k) % len(self.bounds)]
         if hi <= lo:
             return None
         blk = self.src.slice(lo, hi)
@@ -64,7 +64,7 @@ def main():
     import patchcore.common as common
     import patchcore.sampler
     from patchcore.patchcore import AnomalyClusteringCore
-    from patchcore.pipeline import HipOps, shard_bounds, _UnsupJob, lpt_assignment
+    from patchcore.pipeline import HipOps, shard_bounds, _UnsupJob, lpt_assignment, category_rot
     from patchcore.datasets import synthetic
     dev = torch.device("cuda:0")
     core = AnomalyClusteringCore(dev)
@@ -94,14 +94,16 @@ def main():
         return 1e3 * (time.perf_counter() - t0), out
 
     def jobs_for(G, Z):
-        """One _UnsupJob per category for rank 0 of G, prepared, with the local stand-in ring."""
+        """One _UnsupJob per category for rank 0 of G (virtual rank category_rot(c, G): run_categories rotates the shards),
+        prepared, with the local stand-in ring."""
         jobs = {}
-        for c in cats:
+        for ci, c in enumerate(cats):
             bounds = shard_bounds(ns[c], G)
-            job = _UnsupJob(ops, ops.pack(Z[c]), bounds, 0, G, None, dev)
+            v = category_rot(ci, G)
+            job = _UnsupJob(ops, ops.pack(Z[c]), bounds, v, G, None, dev)
             job.m = ops.max_sq([pk_all[c]], dev)                 # what the MAX all-reduce would deliver
             job.prepare()
-            job.ring = LocalRing(ops, src_all[c], bounds, taps_mode)
+            job.ring = LocalRing(ops, src_all[c], bounds, taps_mode, v)
             jobs[c] = job
         return jobs
 
@@ -114,7 +116,10 @@ def main():
     result = {"ring_payload": a.payload, "ring_bytes_per_image": per_image_bytes, "assumed_xgmi_link_GBs": a.link_gbs, "categories": cats, "n": [ns[c] for c in cats], "per_G": {}}
     per_cat_1gpu = None
     for G in a.gpus:
-        shards = {c: images[c][shard_bounds(ns[c], G)[0][0]: shard_bounds(ns[c], G)[0][1]] for c in cats}
+        shards = {c: images[c][shard_bounds(ns[c], G)[0][0]: shard_bounds(ns[c], G)[0][1]] for c in cats}   # sequential: rank 0
+        # pipeline: rank 0 holds the shard of virtual rank category_rot(c, G)
+        shards_p = {c: images[c][shard_bounds(ns[c], G)[category_rot(ci, G)][0]: shard_bounds(ns[c], G)[category_rot(ci, G)][1]]
+                    for ci, c in enumerate(cats)}
         steps = G // 2
 
         def run_sequential():
@@ -144,7 +149,7 @@ def main():
             return job
 
         def run_pipeline():
-            te, Zs = timed(lambda: ops.embed_many([shards[c] for c in cats]))
+            te, Zs = timed(lambda: ops.embed_many([shards_p[c] for c in cats]))
             Z = dict(zip(cats, Zs))
             tp, jobs = timed(lambda: jobs_for(G, Z))                      # pack + norms + accumulators
             t0s, _ = timed(lambda: [jobs[c].run(0) for c in cats])        # step 0 of all categories
@@ -165,7 +170,7 @@ def main():
         if G == 1:
             per_cat_1gpu = best_seq[2]
         # ---- ring timeline, est.: category c's `steps` shards travel concurrently (one link each), categories queue
-        shard_mb = [shard_bounds(ns[c], G)[0][1] * per_image_bytes / 1e6 for c in cats]
+        shard_mb = [shard_bounds(ns[c], G)[0][1] * per_image_bytes / 1e6 for c in cats]       # the full shard (a sender's)
         ms_per_cat = [mb / (a.link_gbs * 1e3) * 1e3 / 1.0 if G > 1 else 0.0 for mb in shard_mb]   # MB / (GB/s) = ms
         # sequential: each category's transfer starts after its own embed + pack and hides under its own step 0 only;
         # take step 0 of a category = its share of t0s (measured jointly), proportional to n^2
@@ -188,6 +193,7 @@ def main():
         pipe_ms = te + tp + t0s + sum(later) + tt
         result["per_G"][G] = {
             "images_on_rank0": sum(int(s.shape[0]) for s in shards.values()),
+            "images_on_rank0_rotated": sum(int(s.shape[0]) for s in shards_p.values()),
             "sequential": {"embed_ms": best_seq[0], "alpha_ms": best_seq[1], "compute_ms": seq_ms,
                            "exposed_ring_ms_est": exposed_seq, "collectives_ms_est": coll,
                            "step_ms_est": seq_ms + exposed_seq + coll,

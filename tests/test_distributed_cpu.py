@@ -450,3 +450,33 @@ def test_ring_of_taps_equals_ring_of_packed_shards(world, mode, many, kw):
                 else:
                     np.testing.assert_array_equal(a, r["alpha"].numpy())
                     np.testing.assert_array_equal(X, r["X"])
+
+
+def _worker_rot(rank, world, init_file, out_dir, mode, rot):
+    sys.path[:0] = [ROOT, MODELS]
+    from patchcore.pipeline import run_category
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    images, train = _inputs()
+    out = run_category(ToyTapsOps(), images, mode, tau=1.0, train_images=train, train_ratio=1.0, rot=rot)
+    np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].numpy())
+    np.save(os.path.join(out_dir, "X_%d.npy" % rank), out["X"])
+    np.save(os.path.join(out_dir, "n_%d.npy" % rank), np.array([out["Z_loc"].shape[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,rot", [(3, "unsupervised", 1), (4, "unsupervised", 3), (3, "supervised", 2), (4, "average", 5)])
+def test_rotated_shards_give_the_same_result(world, mode, rot):
+    """run_category(rot=...): rank r works the shard of virtual rank (r + rot) % world - the ring's peers, the split step
+    and the all-gathers follow - and alpha / X come out in image order, bit-equal to one rank."""
+    from patchcore.pipeline import run_category, shard_bounds
+    images, train = _inputs()
+    ref = run_category(ToyOps(), images, mode, tau=1.0, train_images=train, train_ratio=1.0)
+    bounds = shard_bounds(images.shape[0], world)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_rot, args=(world, os.path.join(d, "rdzv"), d, mode, rot), nprocs=world, join=True)
+        for r in range(world):
+            np.testing.assert_array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].numpy())
+            np.testing.assert_array_equal(np.load(os.path.join(d, "X_%d.npy" % r)), ref["X"])
+            lo, hi = bounds[(r + rot) % world]
+            assert int(np.load(os.path.join(d, "n_%d.npy" % r))[0]) == hi - lo

@@ -302,3 +302,19 @@ def test_bench_workloads_match_baseline_configs():
     assert shard.shape[0] == 10 and shard[3:6].shape[0] == 3
     assert build("5b", n=12)[2] == "unsupervised"
     assert bench.CONFIGS == ("2", "2-pill", "3", "4", "5a", "5b")
+
+
+def test_category_rotation_spreads_the_large_shards():
+    """run_categories rotates the shards of category c by category_rot(c, world): with the 15 MVTec test-set sizes on 8
+    ranks no rank holds the ceil(N / 8) shard of EVERY category any more (221 images on seven ranks and 178 on the last
+    without rotation; 212-219 with it)."""
+    from patchcore.pipeline import category_rot, shard_bounds
+    sizes = [83, 150, 132, 117, 78, 110, 124, 115, 167, 160, 117, 42, 100, 79, 151]
+    world = 8
+    plain = [sum(shard_bounds(n, world)[r][1] - shard_bounds(n, world)[r][0] for n in sizes) for r in range(world)]
+    rotated = [sum(shard_bounds(n, world)[(r + category_rot(c, world)) % world][1] - shard_bounds(n, world)[(r + category_rot(c, world)) % world][0]
+                   for c, n in enumerate(sizes)) for r in range(world)]
+    assert sum(plain) == sum(rotated) == 1725 and max(plain) == 221
+    assert plain[:7] == [221] * 7 and plain[7] == 178            # seven ranks carry the ceil() shard of every category
+    assert max(rotated) <= 219 and max(rotated) - min(rotated) <= 7
+    assert category_rot(5, 1) == 0 and [category_rot(c, 3) for c in range(4)] == [0, 1, 2, 0]
