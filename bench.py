@@ -287,8 +287,10 @@ def _free_port():
 
 def visible_gpus():
     """GPUs this process may use, counted WITHOUT loading the HIP runtime: the KFD topology nodes that have SIMDs
-    (/sys/class/kfd/kfd/topology/nodes/*/properties: CPU nodes say simd_count 0), cut by HIP_VISIBLE_DEVICES /
-    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.  0 when there is no KFD (no GPU driver)."""
+    (/sys/class/kfd/kfd/topology/nodes/*/properties: CPU nodes say simd_count 0), cut by the number of render nodes
+    under /dev/dri and by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.  0 when
+    there is no KFD (no GPU driver).  (A rank that finds fewer devices than its LOCAL_RANK needs exits non-zero, which
+    ends the launch: an over-count here costs a clean failure, never a hang.)"""
     import glob
     n = 0
     for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
@@ -299,6 +301,9 @@ def visible_gpus():
                     n += 1
         except (OSError, ValueError):
             pass
+    render = glob.glob("/dev/dri/renderD*")          # a container may be handed fewer render nodes than the host has GPUs
+    if os.path.isdir("/dev/dri"):
+        n = min(n, len(render))
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
