@@ -308,7 +308,10 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
   if (v == 109) return gemm5::launch<EpiPairMin, 4, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
   if (v == 108) return gemm5::launch<EpiPairMin>(A, B, M, N, K, epi, stream, 4, part, nparts);   // single accumulation
 #endif
-  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts);
+#ifndef AC_PAIR_DYNAMIC
+#define AC_PAIR_DYNAMIC 1           // dynamic tile queues for launches of >= 4 tiles per CU (gemm_hl2.h); 0: A/B builds
+#endif
+  return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts, false, AC_PAIR_DYNAMIC != 0);
 }
 
 __global__ void fill_u32_kernel(unsigned* p, size_t n, unsigned v) {

@@ -40,7 +40,20 @@ using Frag = gemm::FragT<16>;   // v_mfma_f32_16x16x32_f16: 4x4 tiles of 16x16 p
 constexpr int BM = 256, BN = 128, BK = 32, NSTAGE = 3, THREADS = 512;
 constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 KB
 constexpr int LDS_BYTES = NSTAGE * STAGE;                                           // 144 KB
+constexpr int LDS_EXTRA = 16;                                                       // the next tile id of a dynamic walk
 constexpr int FLUSH_STAGES = 16;
+
+// DYNAMIC tile queues (round 4; launch(..., dynamic = true)).  One workgroup per CU walks tiles it PULLS: eight queues,
+// one per XCD slot (blockIdx & 7), queue x handing out the block ids x, x + 8, x + 16, ... in order - exactly the tiles
+// and the order the hardware dispatcher gives that XCD in a one-workgroup-per-tile launch, so the L2 locality of the
+// rasterisation is unchanged - and a workgroup whose own queue is empty steals from the others.  Why: equal tile
+// counts per XCD do not finish together (sampled stamps, profiles/r04_allpairs_tile_timing.txt: the eight XCDs end
+// 1.35 ms apart on a 42 ms launch); stealing evens that out, and the workgroup launch between two tiles goes away.
+// Counters: QUEUE_SLOTS sets of 8 tickets + 1 exit count in device memory, one set per launch in rotation (a set is
+// zero when a launch starts: the last workgroup to leave resets it; two launches share a set only if QUEUE_SLOTS launches
+// are in flight on the device at once).  Every workgroup leaves when all eight queues are exhausted: no spinning.
+constexpr int QUEUE_SLOTS = 64, QUEUE_STRIDE = 16;
+static __device__ unsigned g_tile_queues[QUEUE_SLOTS * QUEUE_STRIDE];
 
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE=1 no DMA issue in the loop, 2 no
 // fragment reads after stage 0, 4 no MFMAs (combinable).  0 in every shipped build.
@@ -143,7 +156,7 @@ __device__ inline bool tile_of(int id, int tiles_m, int tiles_n, int group_m, in
 template <class Epi, bool FLUSH>
 __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
-                                                     int id_lo, int id_hi, int stagger, Epi epi) {
+                                                     int id_lo, int id_hi, int stagger, Epi epi, unsigned* queue) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,10 +215,54 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   };
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
 
+  // dynamic walk (queue != nullptr): thread 0 pulls the next block id - own queue first, then the others' - and hands it
+  // to the workgroup through LDS; -1 = every queue is exhausted
+  int* const lds_next = reinterpret_cast<int*>(smem + LDS_BYTES);
+  // Two steps, so that the ticket's round trip overlaps other memory latency instead of stalling wave 0: take() issues
+  // the atomic on the workgroup's OWN queue (the returned value is not touched yet); resolve() - later - turns it into a
+  // block id, steals from the other queues only when the own one is exhausted (the tail of the launch), and publishes.
+  // (take() is inline assembly: hipcc's atomic optimiser rewrites an atomicAdd in divergent code into a wave reduction
+  // whose v_readfirstlane consumes the result at once - a full memory round trip with wave 0 parked right after the k
+  // loop.  The compiler's own vmcnt bookkeeping stays correct with one more, OLDER operation in flight: counted waits
+  // can only become stricter.)
+  auto take = [&]() -> unsigned {                  // thread 0 only
+    unsigned ticket;
+    unsigned* addr = queue + (blockIdx.x & 7);
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(addr), "v"(1u) : "memory");
+    return ticket;
+  };
+  auto resolve = [&](unsigned ticket) {            // thread 0 only
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");   // the ticket has arrived
+    const int x = blockIdx.x & 7;
+    long long cand = (long long)id_lo + 8ll * ticket + x;
+    int got = cand < id_hi ? (int)cand : -1;
+    for (int j = 1; j < 8 && got < 0; ++j) {
+      const int y = (x + j) & 7;
+      cand = (long long)id_lo + 8ll * atomicAdd(queue + y, 1u) + y;
+      if (cand < id_hi) got = (int)cand;
+    }
+    *lds_next = got;
+  };
+  auto leave = [&]() {                             // thread 0 only: the last workgroup out zeroes the counters
+    if (atomicAdd(queue + 8, 1u) == gridDim.x - 1) {
+      for (int j = 0; j < 9; ++j) atomicExch(queue + j, 0u);
+    }
+  };
+
   // first tile of this workgroup
-  int id = id_lo + blockIdx.x;
-  while (id < id_hi && !setup(id)) id += gridDim.x;
-  if (id >= id_hi) return;
+  int id;
+  if (queue) {
+    if (tid == 0) resolve(take());
+    __syncthreads();
+    id = *lds_next;
+    __syncthreads();                               // everyone has read it before thread 0 may overwrite it
+    if (id < 0) { if (tid == 0) leave(); return; }
+    setup(id);
+  } else {
+    id = id_lo + blockIdx.x;
+    while (id < id_hi && !setup(id)) id += gridDim.x;
+    if (id >= id_hi) return;
+  }
   issue(0);
   if (nk > 1) issue(1);
 
@@ -287,9 +344,14 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     // epilogues that use LDS themselves issue after they are done instead)
     int next = id + gridDim.x;
     bool has_next = false;
-    while (next < id_hi && !(has_next = setup(next))) next += gridDim.x;
     constexpr bool kUsesLds = !SWAP && (EpiTraits<Epi>::kStaged || EpiTraits<Epi>::kSymmetric);
-    if (has_next && !kUsesLds) { issue(0); if (nk > 1) issue(1); }
+    unsigned ticket = 0;
+    if (queue) {
+      if (tid == 0) ticket = take();                 // in flight beside the epilogue's own loads; resolved after the epilogue
+    } else {
+      while (next < id_hi && !(has_next = setup(next))) next += gridDim.x;
+      if (has_next && !kUsesLds) { issue(0); if (nk > 1) issue(1); }
+    }
 
     const int m_wave = m0 + wm * 64, n_wave = n0 + wn * 64;
     if constexpr (SWAP) {
@@ -339,6 +401,20 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     barrier();
     AC_STAMP(3);
 #endif
+    if (queue) {
+      if (tid == 0) resolve(ticket);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // thread 0's block id is in LDS; everyone is out of the ring
+      barrier();
+      next = *lds_next;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      barrier();                                   // ... and has read the ticket before the next pull overwrites it
+      if (next < 0) { if (tid == 0) leave(); break; }
+      setup(next);
+      issue(0);
+      if (nk > 1) issue(1);
+      id = next;
+      continue;
+    }
     if (!has_next) break;
     if (kUsesLds) {                                // the epilogue used the ring: everyone must be out of it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -356,7 +432,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 // all-pairs problem over several GPUs.
 template <class Epi, bool FLUSH = false>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
-                  int group_m = 8, int part = 0, int nparts = 1, bool persistent = false) {
+                  int group_m = 8, int part = 0, int nparts = 1, bool persistent = false, bool dynamic = false) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl2: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl2: bad part %d/%d", part, nparts);
@@ -371,7 +447,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   }
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl2: grid too large");
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
-  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, FLUSH>), LDS_BYTES, &attr_done)) return rc;
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, FLUSH>), LDS_BYTES + LDS_EXTRA, &attr_done)) return rc;
   long long lo = (total * part / nparts) & ~7LL;
   long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
@@ -381,13 +457,24 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   // overlapped prologue gains - so the hardware dispatcher keeps the job; `persistent` is for A/B runs.)
   const int n_cu = ac_device_cus();
   long long grid = (persistent && hi - lo > n_cu) ? n_cu : hi - lo;
+  // dynamic walk: worth it (and only meaningful) when every CU gets several tiles
+  unsigned* queue = nullptr;
+  if (dynamic && hi - lo >= 4ll * n_cu) {
+    static unsigned next_slot = 0;
+    void* base = nullptr;
+    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_tile_queues)) != hipSuccess || !base)
+      return ac_fail(AC_ELAUNCH, "gemm_hl2: hipGetSymbolAddress(g_tile_queues) failed");
+    const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % QUEUE_SLOTS;
+    queue = static_cast<unsigned*>(base) + slot * QUEUE_STRIDE;
+    grid = n_cu;
+  }
   int stagger_arg = 0;
 #ifdef AC_TILE_TIMING
   stagger_arg = tt_counter()++ & 7;
 #endif
-  hipLaunchKernelGGL((kernel<Epi, FLUSH>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream,
+  hipLaunchKernelGGL((kernel<Epi, FLUSH>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
-                     group_m, (int)lo, (int)hi, stagger_arg, epi);
+                     group_m, (int)lo, (int)hi, stagger_arg, epi, queue);
   return ac_check_launch("gemm_hl2");
 }
 
