@@ -23,9 +23,11 @@
 //     group A's P1(t+1) (A at the end of P2(t), B at the end of P1(t)).  Reuse: the ring slot of stage
 //     t+2 was last read in P1(t-1), which both groups left (lgkmcnt(0) + barrier) before either issues
 //     into it.
-//   * PERSISTENT: the grid is one workgroup per CU; each walks tiles id, id+grid, ...  The first two
+//   * PERSISTENT (A/B knob): the grid is one workgroup per CU; each walks tiles id, id+grid, ...  The first two
 //     stages of the NEXT tile are issued before the epilogue of the current one, so the epilogue and the
 //     DMA latency of the next tile's prologue overlap (K = 768 GEMMs spent ~30 % of their time there).
+//   * DYNAMIC (round 4, the all-pairs launches): persistent workgroups PULL tiles from per-XCD-slot queues with
+//     stealing - see g_tile_queues below.
 // Measured (MI355X, K = 4096 all-pairs): 66 % MFMA-pipe utilisation at the 1.72-1.81 GHz the chip
 // sustains under this load; LDS-DMA vs register staging and block-issue vs interleaved DMA issue were
 // all within 2 % of each other (profiles/).
