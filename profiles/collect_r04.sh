@@ -8,7 +8,7 @@ CFG=${1:-2}
 TAG=${2:-bench}
 STEPS=${3:-5}
 O=$R/gpurun_out/prof_r04_$TAG
-rm -rf $O; mkdir -p $O/flat
+rm -rf $O; mkdir -p $O/flat   # (merge note: delete the local gpurun_out/prof_* directory before re-running, or stale *_kernel_stats.csv files of earlier runs stay beside the new one)
 B="python3 $R/bench.py --config $CFG"
 timeout 900 $B --steps $STEPS --warmup 1 > $O/bench_plain.json 2>$O/bench_plain.err || exit 1
 echo "plain bench done"

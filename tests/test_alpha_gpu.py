@@ -159,6 +159,35 @@ def test_partitioned_symmetric_slices_combine_to_the_whole(dev):
     assert torch.equal(w_part, w[1:3])
 
 
+def test_dynamic_tile_queues_on_sliced_and_repeated_launches(dev):
+    """Round 4: launches of >= 4 tiles per CU walk their tiles through per-XCD-slot queues with stealing (gemm_hl2.h).
+    28 images x 784 patches = 86 x 172 tiles of the triangle: the whole launch and its slices (id_lo != 0, slice
+    boundaries at multiples of 8) all take the dynamic walk.  The MIN over the slices equals the whole, bit for bit; the
+    whole equals the brute-force float64 minima on a sample of cells; and 70 back-to-back launches (more than the 64
+    counter sets that rotate) keep giving the same bits - every launch finds its counters zeroed by the last workgroup of
+    the launch that used them before."""
+    import acnative
+    Zs, _ = clustered_embeddings(28, 784, 128, 4, salt=58)
+    Z = torch.from_numpy(Zs).to(dev)
+    whole = acnative.pair_min_sq_part(Z, 0, 1)
+    assert torch.isfinite(whole).all()
+    for G in (2, 3):
+        parts = [acnative.pair_min_sq_part(Z, r, G) for r in range(G)]
+        assert torch.equal(torch.stack(parts).min(0)[0], whole), G
+    Zd = Z.double()
+    for (j, i) in [(0, 1), (5, 27), (27, 3), (13, 13)]:            # minbuf[j][i*P + p] = min_q |Z[i][p] - Z[j][q]|^2
+        d2 = torch.cdist(Zd[i], Zd[j]).pow(2).min(1)[0]
+        got = whole[j, i * 784:(i + 1) * 784].double()
+        if i == j:
+            assert float(got.max()) <= 5e-3                          # a patch is its own nearest neighbour (|z|^2 ~ 140: fp32-grade zero)
+        else:
+            assert float((got - d2).abs().max()) <= 2e-5 * float(d2.max()) + 1e-6
+    pk = acnative.pack_images(Z)
+    for _ in range(70):
+        again = acnative.pair_block(pk, pk).view(torch.float32)
+    assert torch.equal(again, whole)
+
+
 def test_two_way_block_against_one_way_blocks(dev):
     """The two-way launch (a rectangle between two different image sets, every tile reduced in both
     directions): the forward matrix is exactly what a one-way launch fills; the transposed matrix holds the
