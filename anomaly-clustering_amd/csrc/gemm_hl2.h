@@ -463,9 +463,15 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   unsigned* queue = nullptr;
   if (dynamic && hi - lo >= 4ll * n_cu) {
     static unsigned next_slot = 0;
-    void* base = nullptr;
-    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_tile_queues)) != hipSuccess || !base)
-      return ac_fail(AC_ELAUNCH, "gemm_hl2: hipGetSymbolAddress(g_tile_queues) failed");
+    static void* base_of[64] = {};                 // per device: the address of this module's counters there
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ac_fail(AC_ELAUNCH, "gemm_hl2: hipGetDevice failed");
+    void* base = __atomic_load_n(&base_of[dev], __ATOMIC_RELAXED);
+    if (!base) {
+      if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_tile_queues)) != hipSuccess || !base)
+        return ac_fail(AC_ELAUNCH, "gemm_hl2: hipGetSymbolAddress(g_tile_queues) failed");
+      __atomic_store_n(&base_of[dev], base, __ATOMIC_RELAXED);
+    }
     const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % QUEUE_SLOTS;
     queue = static_cast<unsigned*>(base) + slot * QUEUE_STRIDE;
     grid = n_cu;

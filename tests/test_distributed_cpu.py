@@ -480,3 +480,45 @@ def test_rotated_shards_give_the_same_result(world, mode, rot):
             np.testing.assert_array_equal(np.load(os.path.join(d, "X_%d.npy" % r)), ref["X"])
             lo, hi = bounds[(r + rot) % world]
             assert int(np.load(os.path.join(d, "n_%d.npy" % r))[0]) == hi - lo
+
+
+def _worker_eight(rank, world, init_file, out_dir, mode, many):
+    sys.path[:0] = [ROOT, MODELS]
+    torch.set_num_threads(1)
+    from patchcore.pipeline import run_category, run_categories
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(31)
+    images, train = torch.randn(19, 3, 16, 16, generator=g), torch.randn(21, 3, 16, 16, generator=g)
+    ops = ToyTapsPrunedOps(7, [3]) if mode == "supervised" else ToyTapsOps()
+    if many:
+        items = [{"images": images, "train_images": train}, {"images": images[:5], "train_images": train[:9]},
+                 {"images": images[3:16], "train_images": train[2:]}]
+        outs = run_categories(ops, items, mode, tau=1.0, train_ratio=1.0)
+    else:
+        outs = [run_category(ops, images, mode, tau=1.0, train_images=train, train_ratio=1.0)]
+    if rank in (0, 5, 7):
+        for c, o in enumerate(outs):
+            np.save(os.path.join(out_dir, "alpha_%d_%d.npy" % (rank, c)), o["alpha"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,many", [("unsupervised", False), ("supervised", False), ("unsupervised", True)])
+def test_eight_ranks_as_the_driver_will_launch_them(mode, many):
+    """World size 8 - what `bench.py --gpus 8` runs - over gloo with the taps ring: 19 images give the shards 3 3 3 3 3 3 1 0
+    (a short one and an EMPTY one), four ring steps with the split step 4 (unsupervised), seven bank-shard steps and an
+    overflow raised on rank 3 only (supervised), rotated shards over three categories (many).  Equal to one rank."""
+    from patchcore.pipeline import run_category
+    g = torch.Generator().manual_seed(31)
+    images, train = torch.randn(19, 3, 16, 16, generator=g), torch.randn(21, 3, 16, 16, generator=g)
+    sets = [(images, train), (images[:5], train[:9]), (images[3:16], train[2:])] if many else [(images, train)]
+    ref = [run_category(ToyOps(), a, mode, tau=1.0, train_images=b, train_ratio=1.0) for a, b in sets]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_eight, args=(8, os.path.join(d, "rdzv"), d, mode, many), nprocs=8, join=True)
+        for rk in (0, 5, 7):
+            for c, r in enumerate(ref):
+                a = np.load(os.path.join(d, "alpha_%d_%d.npy" % (rk, c)))
+                if mode == "supervised":
+                    np.testing.assert_allclose(a, r["alpha"].numpy(), rtol=1e-6)
+                else:
+                    np.testing.assert_array_equal(a, r["alpha"].numpy())
