@@ -551,8 +551,8 @@ def main():
                    "categories": len(items), "vit_batch": args.batch, "alpha_schedule": args.schedule,
                    "category_schedule": args.category_schedule if len(items) > 1 else None,
                    "minbuf_budget_mb": args.budget_mb,
-                   "parallelism": "images of each category sharded over %d rank(s); RCCL all-gather of packed "
-                                  "shards / ring of shards, all-gather of X and alpha" % world},
+                   "parallelism": "images of each category sharded over %d rank(s); ring of the shards' tapped ViT feature "
+                                  "maps over xGMI (P2P), int64 all-reduce of the sums, RCCL all-gather of X and alpha" % world},
         "roofline": roof,
     }
     if not args.no_extras:
