@@ -306,6 +306,77 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_kernel(AggParams prm
   *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
 }
 
+// ---- the same, one workgroup per ROW of patches (round 4).  Adjacent patches share six of their nine neighbour tokens:
+// the workgroup slides a 3 x 3 window of standardised tokens along the row, loading the three tokens of the new column per
+// step (3 x 12 bytes per thread) instead of nine - a third of the L2 reads and 1 / W0 of the workgroups (one per (patch,
+// layer) was 130 000 launches of ~20 instructions of useful work at 83 images).  Same window sums in the same order:
+// bit-identical.  Columns are kept in four named register sets rotated by a 4-step unrolled loop (no copies); the loads
+// of column x + 2 fly while patch x is summed.  Small batches (a rank's 11 images) keep one workgroup per patch: a row
+// per workgroup would leave the chip a third full.
+__global__ __launch_bounds__(256) void agg_pool_tokens_27_8_row_kernel(AggParams prm) {
+  const int t = threadIdx.x;
+  const int y = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
+  if (t * 8 >= prm.pre) return;
+  const AggLayer L = prm.layer[l];
+  const int HW = L.H * L.W;
+  const float* img = L.f + ((size_t)b * (HW + 1) + 1) * L.C + 3 * t;
+  const float mean = L.norm[b * 2], rstd = L.norm[b * 2 + 1];
+  // one column of the window: the standardised tokens (y-1, xx), (y, xx), (y+1, xx) - zeros outside the map (Unfold pads
+  // with zeros AFTER the LayerNorm) - as [row][channel]
+  auto load_col = [&](int xx, float (&c)[3][3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y + r - 1;
+      const bool inb = (yy >= 0 && yy < L.H && xx >= 0 && xx < L.W);
+      const int yc = min(max(yy, 0), L.H - 1), xc = min(max(xx, 0), L.W - 1);
+      const F3 f = *reinterpret_cast<const F3*>(img + (size_t)(yc * L.W + xc) * L.C);      // unconditional
+      c[r][0] = inb ? (f.a - mean) * rstd : 0.f;
+      c[r][1] = inb ? (f.b - mean) * rstd : 0.f;
+      c[r][2] = inb ? (f.c - mean) * rstd : 0.f;
+    }
+  };
+  // patch x from the columns x-1 (c0), x (c1), x+1 (c2): v[c * 9 + kk], kk = row * 3 + column (the e-order of the unfold)
+  auto emit = [&](int x, const float (&c0)[3][3], const float (&c1)[3][3], const float (&c2)[3][3]) {
+    float v[27];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        v[ch * 9 + r * 3 + 0] = c0[r][ch];
+        v[ch * 9 + r * 3 + 1] = c1[r][ch];
+        v[ch * 9 + r * 3 + 2] = c2[r][ch];
+      }
+    float out[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int s = (q * 27) / 8, e = ((q + 1) * 27 + 7) / 8;                 // adaptive_avg_pool1d window, local
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 27; ++i)
+        if (i >= s && i < e) acc += v[i];
+      out[q] = (e - s) == 4 ? acc * 0.25f : acc / (float)(e - s);            // x / 4 == x * 0.25 exactly
+    }
+    float* o = prm.Z + ((size_t)b * prm.H0 * prm.W0 + (size_t)y * prm.W0 + x) * prm.tgt + l * prm.pre + 8 * t;
+    *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+  };
+  // four column sets: the loads of column x + 2 are in flight while patch x is summed and stored
+  float ca[3][3], cb[3][3], cc[3][3], cd[3][3];
+  load_col(-1, ca);
+  load_col(0, cb);
+  load_col(1, cc);
+  int x = 0;
+  for (; x + 3 < prm.W0; x += 4) {                     // four patches per trip: the column sets rotate by name
+    load_col(x + 2, cd); emit(x, ca, cb, cc);
+    load_col(x + 3, ca); emit(x + 1, cb, cc, cd);
+    load_col(x + 4, cb); emit(x + 2, cc, cd, ca);
+    load_col(x + 5, cc); emit(x + 3, cd, ca, cb);
+  }
+  if (x < prm.W0) { load_col(x + 2, cd); emit(x, ca, cb, cc); ++x; }
+  if (x < prm.W0) { load_col(x + 2, ca); emit(x, cb, cc, cd); ++x; }
+  if (x < prm.W0) { emit(x, cc, cd, ca); }
+}
+
 extern "C" size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C, const int* H, const int* W, int B,
                                                      int patchsize, int pre_dim, int tgt_dim) {
   (void)C; (void)H; (void)W; (void)patchsize; (void)pre_dim; (void)tgt_dim;
@@ -361,7 +432,13 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
                tgt_dim % 4 == 0;
   for (int l = 0; l < n_layers && reg27; ++l) reg27 = (3LL * pre_dim == 8LL * C[l]) && C[l] % 3 == 0;
   if (reg27) {
-    hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
+#ifdef AC_AGG_PER_PATCH          // (same-box A/B: round 2's one workgroup per (patch, layer) at every size)
+    const bool per_row = false;
+#else
+    const bool per_row = (long long)H[0] * B * n_layers >= 8LL * ac_device_cus();   // >= 8 row-workgroups per CU
+#endif
+    if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel, dim3(H[0], B, n_layers), dim3(256), 0, stream, prm);
+    else hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
     return ac_check_launch("ac_patch_aggregate(tokens, registers)");
   }
   if (fast) {
