@@ -106,3 +106,24 @@ def test_register_path_equals_generic_path(dev):
     # one layer, and a shape that must NOT take the register path (pre = 1024): still the LDS kernels' answer
     Z1, _ = acnative.patch_aggregate(toks[:1], 3, 2048, 2048)
     np.testing.assert_allclose(Z1.cpu().numpy(), a[:, :2048], rtol=2e-6, atol=1e-6)
+
+
+def test_row_kernel_equals_the_per_patch_kernel_bitwise(dev):
+    """Round 4: batches of >= 8 row-workgroups per CU (here 80 images of the DINO ViT-B/8 shape) run the register kernel
+    with one workgroup per ROW of patches (a sliding 3 x 3 window of standardised tokens); smaller batches keep one
+    workgroup per patch.  The same images through both - one call of 80, four calls of 20 - give the SAME BITS, and three
+    rows of one image (first, interior, last: the zero padding on every side) match the oracle."""
+    import acnative
+    from oracle import aggregate as oagg
+    fa = torch.from_numpy(gaussish_tensor((80, 785, 768), salt=31, scale=1.4)) + 0.2
+    fb = torch.from_numpy(gaussish_tensor((80, 785, 768), salt=32, scale=0.9)) - 0.1
+    fa, fb = fa.to(dev), fb.to(dev)
+    Z_row, _ = acnative.patch_aggregate([fa, fb], 3, 2048, 4096)
+    Z_patch = torch.cat([acnative.patch_aggregate([fa[i:i + 20].contiguous(), fb[i:i + 20].contiguous()], 3, 2048, 4096)[0]
+                         for i in range(0, 80, 20)])
+    assert Z_row.shape == (80 * 784, 4096) and torch.equal(Z_row, Z_patch)
+    ref = oagg.aggregate([fa[7:8].cpu(), fb[7:8].cpu()], 3, 2048, 4096)[0].numpy()
+    mine = Z_row[7 * 784: 8 * 784].cpu().numpy()
+    for rows in (slice(0, 28), slice(13 * 28, 14 * 28), slice(27 * 28, 28 * 28)):
+        ok, mx = _close(mine[rows], ref[rows])
+        assert ok, mx
