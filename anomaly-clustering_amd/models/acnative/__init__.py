@@ -147,12 +147,23 @@ def release_workspaces():
 
 
 # ------------------------------------------------------------------ operands
-def pack_hl32(mat, want_sqnorm=False):
-    """fp32 [rows, K] -> hl32 image (uint8 [rows, K*4]) (+ fp32 [rows] squared norms)."""
+def pack_hl32(mat, want_sqnorm=False, out=None, sq_out=None):
+    """fp32 [rows, K] -> hl32 image (uint8 [rows, K*4]) (+ fp32 [rows] squared norms).  out / sq_out: contiguous
+    device tensors of those shapes to write into (a block of rows of a larger image)."""
     p = _dev(mat, torch.float32, "mat")
     rows, K = mat.shape
-    out = torch.empty((rows, K * 4), dtype=torch.uint8, device=mat.device)
-    sq = torch.empty((rows,), dtype=torch.float32, device=mat.device) if want_sqnorm else None
+    if out is None:
+        out = torch.empty((rows, K * 4), dtype=torch.uint8, device=mat.device)
+    else:
+        _dev(out, torch.uint8, "out")
+        if tuple(out.shape) != (rows, K * 4):
+            raise ValueError("pack_hl32: out must be uint8 [%d, %d], got %s" % (rows, K * 4, tuple(out.shape)))
+    sq = None
+    if want_sqnorm:
+        sq = torch.empty((rows,), dtype=torch.float32, device=mat.device) if sq_out is None else sq_out
+        if tuple(sq.shape) != (rows,):
+            raise ValueError("pack_hl32: sq_out must be fp32 [%d], got %s" % (rows, tuple(sq.shape)))
+        _dev(sq, torch.float32, "sq_out")
     _check(lib().ac_pack_hl32(p, rows, K, K, out.data_ptr(), sq.data_ptr() if want_sqnorm else None, _stream()))
     return (out, sq) if want_sqnorm else out
 
@@ -401,12 +412,18 @@ class Packed:
                       torch.empty((n * P,), dtype=torch.float32, device=device), n, P, D)
 
 
-def pack_images(Z):
-    """Z fp32 [n, P, D] -> Packed (one pass: split-fp16 image + squared norms)."""
+def pack_images(Z, out=None):
+    """Z fp32 [n, P, D] -> Packed (one pass: split-fp16 image + squared norms).  out: a Packed of n images (e.g. a
+    slice of a larger one) that receives the rows instead of a new allocation."""
     _dev(Z, torch.float32, "Z")
     n, P, D = Z.shape
+    if out is not None and (out.n, out.P, out.D) != (n, P, D):
+        raise ValueError("pack_images: out holds %s, Z is %s" % ((out.n, out.P, out.D), (n, P, D)))
     if n == 0:
-        return Packed.empty(0, P, D, Z.device)
+        return out if out is not None else Packed.empty(0, P, D, Z.device)
+    if out is not None:
+        pack_hl32(Z.reshape(n * P, D), want_sqnorm=True, out=out.hl, sq_out=out.sq)
+        return out
     hl, sq = pack_hl32(Z.reshape(n * P, D), want_sqnorm=True)
     return Packed(hl, sq, n, P, D)
 
@@ -700,16 +717,18 @@ def alpha_average(n, P, device):
     return filled((n, P), torch.float32, device, bits)
 
 
-def weighted_avg(alpha, Z):
-    """alpha fp32 [N, P] (or [N,1,P]), Z fp32 [N, P, D] -> X fp32 [N, D]."""
+def weighted_avg(alpha, Z, out=None):
+    """alpha fp32 [N, P] (or [N,1,P]), Z fp32 [N, P, D] -> X fp32 [N, D] (out: contiguous rows to write into)."""
     N, P, D = Z.shape
+    if out is not None and (tuple(out.shape) != (N, D) or out.dtype != torch.float32 or not out.is_contiguous()):
+        raise ValueError("weighted_avg: out must be contiguous fp32 [%d, %d]" % (N, D))
     if N == 0:                           # a rank with an empty image shard
-        return torch.empty((0, D), dtype=torch.float32, device=Z.device)
+        return out if out is not None else torch.empty((0, D), dtype=torch.float32, device=Z.device)
     alpha = alpha.reshape(alpha.shape[0], -1).contiguous()
     pa, pz = _dev(alpha, torch.float32, "alpha"), _dev(Z, torch.float32, "Z")
     if alpha.shape != (N, P):
         raise ValueError("alpha %s does not match Z %s" % (tuple(alpha.shape), tuple(Z.shape)))
-    X = torch.empty((N, D), dtype=torch.float32, device=Z.device)
+    X = torch.empty((N, D), dtype=torch.float32, device=Z.device) if out is None else out
     for s in range(0, N, 32768):
         e = min(N, s + 32768)
         _check(lib().ac_weighted_avg(alpha[s:e].data_ptr(), Z[s:e].data_ptr(), e - s, P, D, X[s:e].data_ptr(),

@@ -147,6 +147,28 @@ class AnomalyClusteringCore(torch.nn.Module):
         return Zr.reshape(n, Zr.shape[0] // n, Zr.shape[-1])
 
     @torch.no_grad()
+    def embed_taps_device(self, images, batch_size=32):
+        """Only the tapped feature maps of the images ([N, ...] per extracted layer, device-resident), no aggregation:
+        what a category too large to hold Z (12.85 MB per image) next to its packed copy keeps instead - 4.8 MB per
+        image for ViT-B/8, from which aggregate_taps rebuilds any block of Z bit for bit."""
+        N = images.shape[0]
+        bufs = None
+        _ = self.forward_modules["feature_aggregator"].eval()
+        for s in range(0, N, batch_size):
+            chunk = images[s:s + batch_size].to(self.device, dtype=torch.float32, non_blocking=True)
+            taps = self.forward_modules["feature_aggregator"](chunk)
+            feats = [taps[layer] for layer in self.layers_to_extract_from]
+            if not all(t.is_contiguous() for t in feats):
+                raise RuntimeError("embed_taps_device needs contiguous feature maps (token maps); this backbone's are strided views")
+            if chunk.shape[0] == N:
+                return feats
+            if bufs is None:
+                bufs = [torch.empty((N,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in feats]
+            for buf, t in zip(bufs, feats):
+                buf[s:s + chunk.shape[0]].copy_(t)
+        return bufs
+
+    @torch.no_grad()
     def embed_device_many(self, image_sets, batch_size=32, want_taps=False):
         """Several image sets -> [Z_i fp32 [n_i, P, D]] (views of ONE buffer), embedded as one stream of full
         batches: a batch may span set boundaries (its images are then gathered into a staging buffer by

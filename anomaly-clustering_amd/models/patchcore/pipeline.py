@@ -140,6 +140,10 @@ class Taps:
     def empty_like(self, n):
         return Taps([torch.empty((n,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in self.feats], n)
 
+    @property
+    def device(self):
+        return self.feats[0].device
+
 
 class HipOps:
     """Compute seam backed by libac_hip.so.  Every method raises if the library or the GPU is missing."""
@@ -200,6 +204,49 @@ class HipOps:
         if taps.n == 0:
             return self.pack(self._empty(False))
         return self.pack(self.core.aggregate_taps(taps.feats))
+
+    # ---- a category too large for Z next to its packed copy keeps the taps instead of Z (run_category's `lean`)
+    LEAN_CHUNK = 128          # images aggregated at a time when Z is rebuilt from taps (1.6 GB of Z)
+    LEAN_FRACTION = 0.5       # lean when Z + packed of the rank's images would take more than this share of the free HBM
+
+    def zshape(self):
+        """(P, D) of one image's Z."""
+        if self._zshape is None:
+            self._probe()
+        return self._zshape
+
+    def wants_lean(self, n_images):
+        P, D = self.zshape()
+        free, _ = torch.cuda.mem_get_info(self.core.device)
+        return n_images * 2 * P * D * 4 > self.LEAN_FRACTION * free
+
+    def embed_taps(self, images):
+        """Taps of the images, Z never materialised as a whole (25.7 -> 17.7 MB of HBM per image with the packed copy)."""
+        if images.shape[0] == 0:
+            return self._empty(True)[1]
+        feats = self.core.embed_taps_device(images, batch_size=self.batch_size)
+        self._tapshapes = [(tuple(t.shape[1:]), t.dtype) for t in feats]
+        return Taps(feats, int(images.shape[0]))
+
+    def pack_taps(self, taps):
+        """Taps -> Packed, LEAN_CHUNK images at a time: aggregate into a scratch Z, pack into place.  Bit-identical to
+        pack(embed(images)): the same two kernels on the same bytes."""
+        P, D = self.zshape()
+        pk = self.acnative.Packed.empty(taps.n, P, D, taps.device)
+        for s in range(0, taps.n, self.LEAN_CHUNK):
+            e = min(taps.n, s + self.LEAN_CHUNK)
+            self.acnative.pack_images(self.core.aggregate_taps([f[s:e] for f in taps.feats]), out=pk.slice(s, e))
+        return pk
+
+    def weighted_avg_taps(self, alpha_f32, taps):
+        """X = alpha . Z with Z rebuilt from the taps chunk by chunk (main.py:292-296 on a category whose Z was dropped)."""
+        P, D = self.zshape()
+        X = torch.empty((taps.n, D), dtype=torch.float32, device=taps.device)
+        alpha_f32 = alpha_f32.reshape(taps.n, -1)
+        for s in range(0, taps.n, self.LEAN_CHUNK):
+            e = min(taps.n, s + self.LEAN_CHUNK)
+            self.acnative.weighted_avg(alpha_f32[s:e], self.core.aggregate_taps([f[s:e] for f in taps.feats]), out=X[s:e])
+        return X
 
     # ---- packed blocks and the pair kernels (see acnative for the semantics)
     def pack(self, Z):
@@ -646,12 +693,20 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     return ops.pair_finalize(acc, P, MIN, m, None)
 
 
+def _zinfo(ops, Z):
+    """(images, patches per image, device) of a rank's embeddings: Z fp32 [n, P, D], or the Taps a lean run keeps instead."""
+    if isinstance(Z, Taps):
+        return Z.n, ops.zshape()[0], Z.device
+    return Z.shape[0], Z.shape[1], Z.device
+
+
 def _alpha_pair(ops, w_loc, Z_loc, tau, k):
     """(alpha fp64-or-None, alpha fp32 [n_loc, P]) for one tau; w_loc None: the `average` weights (main.py:290-291)."""
     if w_loc is None:
+        n, P, device = _zinfo(ops, Z_loc)
         if hasattr(ops, "alpha_average"):
-            return None, ops.alpha_average(Z_loc.shape[0], Z_loc.shape[1], Z_loc.device)
-        return None, torch.ones(Z_loc.shape[0], Z_loc.shape[1], device=Z_loc.device) / Z_loc.shape[1]
+            return None, ops.alpha_average(n, P, device)
+        return None, torch.ones(n, P, device=device) / P
     res = ops.alpha_softmax(w_loc, tau, k)
     if isinstance(res, tuple):                                             # the kernel wrote main.py:294's `.float()` too
         return res
@@ -667,7 +722,7 @@ def _tail(ops, w_loc, Z_loc, counts, group, rank, tau, k, want_pdist, want_host,
     for tv in taus:
         t0 = time.perf_counter()
         _, alpha_f32 = _alpha_pair(ops, w_loc, Z_loc, tv, k)
-        X_loc = ops.weighted_avg(alpha_f32, Z_loc)
+        X_loc = ops.weighted_avg_taps(alpha_f32, Z_loc) if isinstance(Z_loc, Taps) else ops.weighted_avg(alpha_f32, Z_loc)
         X = all_gather_rows(X_loc, counts, group, rot)
         alpha = all_gather_rows(alpha_f32, counts, group, rot).unsqueeze(1)
         mark("alpha_softmax_weighted_avg_gather", t0)
@@ -694,7 +749,7 @@ def _marker(ops, timings):
 
 def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_images=None, train_ratio=1.0,
                  group=None, bank_seed=0, want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES,
-                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True, solo=False, rot=0):
+                 schedule="auto", Z_loc=None, remote_bytes=REMOTE_BYTES, prune=True, solo=False, rot=0, lean=None):
     """images: [N, 3, H, W] (every rank passes the same N; only the rank's shard is read).
     `tau` may be a list: the embeddings and the patch distances are computed once and every tau gets its
     own (alpha, X) in out["by_tau"][tau]; the top-level keys are those of the first tau.
@@ -709,6 +764,10 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     shard_bounds gives the first ranks ceil(N / world) images and the last one the remainder; a job over many categories
     rotates who is "last" (run_categories) so that no rank holds the large shard of EVERY category.  out["bounds"] is
     indexed by virtual rank; the gathered alpha / X are in image order whatever rot is.
+    lean: keep the tapped feature maps (4.8 MB per image) instead of Z (12.85 MB) next to the packed copy (12.85 MB):
+    the packed blocks and, after alpha, X are built from the taps LEAN_CHUNK images at a time - the same kernels on the
+    same bytes, so nothing in the result changes; out["Z_loc"] is then the Taps (accepted back as `Z_loc`).  None: the
+    seam decides from the free HBM (HipOps.wants_lean: N = 10 000 on one GPU is 257 GB with Z, 177 GB without).
     Returns dict(alpha fp32 [N, 1, P] on device, X float32 ndarray [N, D], X_dev, pdist (rank 0), bounds)."""
     real_rank, world = (0, 1) if solo else _world(group)
     rot = rot % world
@@ -722,15 +781,27 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
     # several ranks: the ring carries the tapped feature maps (4.8 MB per image) instead of packed embeddings (12.85 MB)
     # whenever the seam can turn received taps into packed blocks; the unsupervised "slices" schedule gathers packed Z
     use_taps = world > 1 and getattr(ops, "ring_payload", None) == "taps" and not (supervised == "unsupervised" and schedule == "slices")
+    if isinstance(Z_loc, Taps):
+        lean = True
+    elif Z_loc is not None:
+        lean = False
+    elif lean is None:
+        n_bank = 0 if train_images is None or supervised != "supervised" else -(-min(n, train_images.shape[0]) // world)
+        lean = bool(getattr(ops, "wants_lean", lambda _n: False)((hi - lo) + n_bank))
     taps_loc = None
     t0 = time.perf_counter()
     if Z_loc is None:
-        if use_taps and supervised == "unsupervised":
+        if lean:
+            Z_loc = taps_loc = ops.embed_taps(images[lo:hi])           # Z is never held as a whole
+        elif use_taps and supervised == "unsupervised":
             Z_loc, taps_loc = ops.embed(images[lo:hi], want_taps=True)
         else:
             Z_loc = ops.embed(images[lo:hi])                           # [n_loc, P, D]
-    elif Z_loc.shape[0] != hi - lo:
-        raise ValueError("Z_loc holds %d images, this rank's shard has %d" % (Z_loc.shape[0], hi - lo))
+    else:
+        if _zinfo(ops, Z_loc)[0] != hi - lo:
+            raise ValueError("Z_loc holds %d images, this rank's shard has %d" % (_zinfo(ops, Z_loc)[0], hi - lo))
+        if lean:
+            taps_loc = Z_loc
     mark("embed", t0)
     device = Z_loc.device
 
@@ -742,16 +813,21 @@ def run_category(ops, images, supervised="unsupervised", tau=1.0, k=1, train_ima
         bb = shard_bounds(len(sel), world)
         blo, bhi = bb[rank]
         bank_taps = None
-        if use_taps:
+        if lean:
+            bank_taps = ops.embed_taps(train_images[sel[blo:bhi]])
+            pk_bank = ops.pack_taps(bank_taps)
+        elif use_taps:
             bank_loc, bank_taps = ops.embed(train_images[sel[blo:bhi]], want_taps=True)
+            pk_bank = ops.pack(bank_loc)
+            del bank_loc
         else:
-            bank_loc = ops.embed(train_images[sel[blo:bhi]])
-        w_loc = alpha_weights_supervised(ops, ops.pack(Z_loc), ops.pack(bank_loc), bb, rank, world, group, device, budget,
-                                         remote_bytes, prune, send=bank_taps, rot=rot)
-        del bank_loc, bank_taps
+            pk_bank = ops.pack(ops.embed(train_images[sel[blo:bhi]]))
+        w_loc = alpha_weights_supervised(ops, ops.pack_taps(taps_loc) if lean else ops.pack(Z_loc), pk_bank, bb, rank, world,
+                                         group, device, budget, remote_bytes, prune, send=bank_taps if use_taps else None, rot=rot)
+        del pk_bank, bank_taps
     elif supervised == "unsupervised":
-        w_loc = alpha_weights_unsupervised(ops, ops.pack(Z_loc), bounds, rank, world, group, device, budget, schedule,
-                                           remote_bytes, send=taps_loc, rot=rot)
+        w_loc = alpha_weights_unsupervised(ops, ops.pack_taps(taps_loc) if lean else ops.pack(Z_loc), bounds, rank, world, group,
+                                           device, budget, schedule, remote_bytes, send=taps_loc if use_taps else None, rot=rot)
         taps_loc = None
     else:                                                              # "average" (main.py:290-291)
         w_loc = None

@@ -77,6 +77,11 @@ def parse():
     ap.add_argument("--collective-timeout", type=float, default=None,
                     help="timeout of the process group in seconds (default: 120 s, config 5: 3600 s - a collective queued "
                          "behind minutes of MFMA work completes that late)")
+    ap.add_argument("--lean", default="auto", choices=["auto", "on", "off"],
+                    help="configs 2 / 5: keep the ViT taps (4.8 MB per image) instead of Z (12.85 MB) next to the packed copy; "
+                         "auto = when Z + packed would not fit (N = 10 000 on one GPU)")
+    ap.add_argument("--heartbeat", type=float, default=None,
+                    help="seconds between progress lines on stderr (default: 60 for config 5, whose step runs for minutes; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, nargs="+", default=[32, 83],
                     help="category sizes at which the CPU baseline is MEASURED (N=83 takes about a minute of host time)")
@@ -444,9 +449,24 @@ def main():
     n_total = sum(len(it["labels"]) for it in items)
     budget = args.budget_mb << 20
 
+    lean = {"auto": None, "on": True, "off": False}[args.lean]
+
     def run_item(it, images, timings=None):
         return run_category(ops, images, mode, tau=args.tau, train_images=it.get("train"), train_ratio=1.0,
-                            want_host=False, timings=timings, budget=budget, schedule=args.schedule)
+                            want_host=False, timings=timings, budget=budget, schedule=args.schedule, lean=lean)
+
+    beat = args.heartbeat if args.heartbeat is not None else (60.0 if args.config.startswith("5") else 0.0)
+    if beat > 0 and rank == 0:                              # a step of config 5b is queued in seconds and runs for minutes
+        import threading
+        t_start = time.time()
+
+        def heartbeat():
+            while True:
+                time.sleep(beat)
+                free, total = torch.cuda.mem_get_info(dev)
+                print("bench.py: %d s, %.1f of %.1f GB of HBM in use" % (time.time() - t_start, (total - free) / 1e9, total / 1e9),
+                      file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
 
     many = len(items) > 1 and args.category_schedule != "sequential"
 
@@ -551,6 +571,7 @@ def main():
                    "categories": len(items), "vit_batch": args.batch, "alpha_schedule": args.schedule,
                    "category_schedule": args.category_schedule if len(items) > 1 else None,
                    "minbuf_budget_mb": args.budget_mb,
+                   "lean": None if len(items) > 1 else not isinstance(last[0].get("Z_loc"), torch.Tensor),
                    "parallelism": "images of each category sharded over %d rank(s); ring of the shards' tapped ViT feature "
                                   "maps over xGMI (P2P), int64 all-reduce of the sums, RCCL all-gather of X and alpha" % world},
         "roofline": roof,

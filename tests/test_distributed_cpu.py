@@ -391,9 +391,24 @@ class ToyTapsOps(ToyOps):
         flat = images.reshape(n, -1)[:, : self.P * self.D].contiguous() if n else torch.zeros(0, self.P * self.D)
         return Z, Taps([flat], n)
 
-    def taps_to_packed(self, taps):
+    def _z(self, taps):
         f = taps.feats[0].reshape(taps.n, self.P, self.D)
-        return self.pack((f * 1.5 + f.roll(1, dims=2) * 0.5).contiguous())
+        return (f * 1.5 + f.roll(1, dims=2) * 0.5).contiguous()
+
+    def taps_to_packed(self, taps):
+        return self.pack(self._z(taps))
+
+    # the seam of run_category's `lean` mode (HipOps.embed_taps / pack_taps / weighted_avg_taps): Z is never kept
+    def zshape(self):
+        return (self.P, self.D)
+
+    def embed_taps(self, images):
+        return self.embed(images, want_taps=True)[1]
+
+    pack_taps = taps_to_packed
+
+    def weighted_avg_taps(self, alpha_f32, taps):
+        return self.weighted_avg(alpha_f32.reshape(taps.n, -1), self._z(taps))
 
 
 class ToyTapsPrunedOps(ToyTapsOps, ToyPrunedOps):
@@ -426,6 +441,9 @@ def _worker_taps(rank, world, init_file, out_dir, mode, many, kw):
     (3, "supervised_pruned", False, {}),
     (3, "unsupervised", True, {}),
     (4, "supervised_pruned", True, {}),
+    (3, "unsupervised", False, {"lean": True}),               # Z dropped: packed blocks and X rebuilt from the taps
+    (2, "supervised", False, {"lean": True}),
+    (2, "average", False, {"lean": True}),
 ])
 def test_ring_of_taps_equals_ring_of_packed_shards(world, mode, many, kw):
     """Several ranks send the tapped feature maps round the ring (2.7x fewer bytes on the real shapes) and the receiver

@@ -42,7 +42,7 @@ def _images():
     return test, train
 
 
-def _worker(rank, world, init_file, mode, out_dir):
+def _worker(rank, world, init_file, mode, out_dir, lean=None):
     sys.path[:0] = [ROOT, MODELS]
     from patchcore.pipeline import HipOps, run_category
     dev = torch.device("cuda:0")
@@ -50,7 +50,9 @@ def _worker(rank, world, init_file, mode, out_dir):
     dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
     core = _build(dev)
     test, train = _images()
-    out = run_category(HipOps(core, batch_size=4), test.to(dev), mode, tau=1.0, train_images=train.to(dev))
+    ops = HipOps(core, batch_size=4)
+    ops.LEAN_CHUNK = 3
+    out = run_category(ops, test.to(dev), mode, tau=1.0, train_images=train.to(dev), lean=lean)
     np.save(os.path.join(out_dir, "alpha_%d.npy" % rank), out["alpha"].cpu().numpy())
     np.save(os.path.join(out_dir, "X_%d.npy" % rank), out["X"])
     dist.barrier()
@@ -72,6 +74,33 @@ def test_two_ranks_on_one_gpu_match_one_rank(dev, mode):
             # A ViT batch of another size gives every image the same bits (the GEMM kernels accumulate each output
             # row in one fixed K order), so two ranks equal one rank exactly
             assert np.array_equal(a, ref["alpha"].cpu().numpy()) and np.array_equal(X, ref["X"])
+
+
+@pytest.mark.parametrize("mode", ["unsupervised", "supervised", "average"])
+def test_lean_run_keeps_taps_instead_of_Z(dev, mode):
+    """run_category(lean=True): the rank keeps the ViT taps (4.8 MB per image) instead of Z (12.85 MB); the packed blocks
+    and X are rebuilt from them chunk by chunk (chunks of 3 here: 3 + 3 + 1 images) by the same kernels on the same
+    bytes - alpha, X and the distances equal the run that holds Z, bit for bit, on one rank and on two."""
+    from patchcore.pipeline import HipOps, Taps, run_category
+    core = _build(dev)
+    test, train = _images()
+    ops = HipOps(core, batch_size=4)
+    ops.LEAN_CHUNK = 3
+    assert not ops.wants_lean(7) and ops.wants_lean(10 ** 6)
+    ref = run_category(ops, test.to(dev), mode, tau=1.0, train_images=train.to(dev), lean=False)
+    out = run_category(ops, test.to(dev), mode, tau=1.0, train_images=train.to(dev), lean=True)
+    assert isinstance(out["Z_loc"], Taps) and out["Z_loc"].n == 7 and isinstance(ref["Z_loc"], torch.Tensor)
+    again = run_category(ops, test.to(dev), mode, tau=1.0, train_images=train.to(dev), Z_loc=out["Z_loc"])
+    for o in (out, again):
+        assert torch.equal(o["alpha"], ref["alpha"]) and np.array_equal(o["X"], ref["X"])
+        assert torch.equal(o["pdist"], ref["pdist"])
+    if mode == "average":
+        return
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, os.path.join(d, "rdzv"), mode, d, True), nprocs=2, join=True)
+        for r in range(2):
+            assert np.array_equal(np.load(os.path.join(d, "alpha_%d.npy" % r)), ref["alpha"].cpu().numpy())
+            assert np.array_equal(np.load(os.path.join(d, "X_%d.npy" % r)), ref["X"])
 
 
 def _worker_small(rank, world, init_file, out_dir):
