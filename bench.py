@@ -82,6 +82,10 @@ def parse():
                          "auto = when Z + packed would not fit (N = 10 000 on one GPU)")
     ap.add_argument("--heartbeat", type=float, default=None,
                     help="seconds between progress lines on stderr (default: 60 for config 5, whose step runs for minutes; 0 = none)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run the --gpus N ranks on ONE device over gloo (RCCL refuses two ranks per device; N <= 6): a "
+                         "rehearsal of the launcher and of every rank's code path with the real kernels, NOT a measurement - "
+                         "the JSON line says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, nargs="+", default=[32, 83],
                     help="category sizes at which the CPU baseline is MEASURED (N=83 takes about a minute of host time)")
@@ -403,10 +407,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under torchrun: this process becomes the launcher and makes no GPU call at all
         limit = args.launch_timeout if args.launch_timeout is not None else (3300.0 if args.config.startswith("5") else 480.0)
-        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout_s=limit))
+        if args.rehearse_on_one_gpu and args.gpus > 6:
+            raise SystemExit("bench.py --rehearse-on-one-gpu: at most 6 ranks may share the device")
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout_s=limit,
+                              visible_devices=args.gpus if args.rehearse_on_one_gpu and visible_gpus() >= 1 else None))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; the number of ranks must be the number asked for"
                          % (args.gpus, world))
@@ -420,7 +427,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         ct = args.collective_timeout if args.collective_timeout is not None else (3600.0 if args.config.startswith("5") else 120.0)
-        dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=ct))
+        if args.rehearse_on_one_gpu:          # the ranks share cuda:0; gloo stages device tensors through the host
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=ct))
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=ct))
         # RCCL smoke before anything is timed: communicator creation + a 1-element all-reduce
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)
@@ -576,6 +586,9 @@ def main():
                                   "maps over xGMI (P2P), int64 all-reduce of the sums, RCCL all-gather of X and alpha" % world},
         "roofline": roof,
     }
+    if args.rehearse_on_one_gpu and world > 1:
+        out["rehearsal"] = ("%d ranks share ONE GPU over gloo: the multi-rank code path with the real kernels, not a "
+                            "measurement of %d GPUs" % (world, world))
     if not args.no_extras:
         per_cat, stages = [], {}
         step(timings=stages, per_cat=per_cat)                   # one extra, untimed-for-the-metric step

@@ -72,3 +72,19 @@ def test_bench_config_3_all_fifteen_categories(schedule):
 
 def test_bench_config_4_supervised():
     _check_all15(_bench("--config", "4", "--gpus", "1", "--no-cpu-baseline", "--steps", "1"), "supervised")
+
+
+@pytest.mark.parametrize("ranks,extra", [(4, ()), (2, ("--config", "3"))])
+def test_bench_rehearsal_of_the_multi_rank_run_on_one_gpu(ranks, extra):
+    """`bench.py --gpus N` as the driver will call it on the 8-GPU node - the launcher, N fresh rank processes, the process
+    group, the sharded step, the barrier + max-over-ranks clock, rank 0's single JSON line - rehearsed on the ONE GPU of
+    this box: the ranks share the device over gloo (--rehearse-on-one-gpu; RCCL refuses two ranks per device).  The
+    clustering scores of the step must be those of the one-rank run (alpha and X are bit-equal across rank counts)."""
+    common = ("--no-cpu-baseline", "--steps", "1", "--warmup", "0") + tuple(extra)
+    one = _bench("--gpus", "1", *common)
+    d = _bench("--gpus", str(ranks), "--rehearse-on-one-gpu", *common)
+    assert REQUIRED <= set(d) and d["n_gpus"] == ranks and "rehearsal" in d and "rehearsal" not in one
+    assert d["value"] > 0 and d["config"]["images_per_step"] == one["config"]["images_per_step"]
+    assert d["clustering"]["NMI"] == one["clustering"]["NMI"] and d["clustering"]["ARI"] == one["clustering"]["ARI"]
+    assert d["clustering"]["F1"] == one["clustering"]["F1"]
+    assert "cpu_baseline" not in d
