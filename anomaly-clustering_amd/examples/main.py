@@ -236,6 +236,9 @@ def build_parser():
     parser.add_argument('--category_schedule', default="pipeline", choices=["pipeline", "sequential", "per_gpu"],
                         help="pipeline: all categories as one job (pipeline.run_categories); sequential: one category "
                              "after another, as the reference loops them; per_gpu: whole categories to GPUs.")
+    parser.add_argument('--rehearse_on_one_gpu', action="store_true",
+                        help="under torchrun: all ranks share cuda:0 over gloo (RCCL refuses two ranks per device) - a "
+                             "rehearsal of the multi-rank run on a one-GPU box; the artefacts are those of the real run.")
     return parser
 
 
@@ -243,11 +246,17 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        global device
+        if args.rehearse_on_one_gpu:
+            device = torch.device("cuda:0")
         torch.cuda.set_device(device)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # explicit timeout: a rank that dies or hangs ends the job after two minutes instead of never
-        dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=120))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=120))
         probe = torch.ones(1, device=device)             # RCCL smoke before any work: a 1-element all-reduce
         dist.all_reduce(probe)
         if int(probe.item()) != dist.get_world_size():

@@ -206,3 +206,33 @@ def test_cli_categories_as_one_job_write_the_same_artefacts(tmp_path, dev):
         saved = test_mod._safe_load(str(tmp_path / "pipeline") + f)
         assert torch.equal(saved[0], a) and np.array_equal(saved[1], X)
     assert len(test_mod._safe_load(str(tmp_path / "pipeline") + "/synthetic/info/info_grid.pickle")) == 78
+
+
+@pytest.mark.parametrize("schedule", ["pipeline", "sequential"])
+def test_cli_under_torchrun_writes_the_one_process_artefacts(tmp_path, dev, schedule):
+    """`python -m torch.distributed.run --nproc-per-node 2 main.py ...` - how the reference's CLI runs on several GPUs -
+    rehearsed on this box's one GPU (--rehearse_on_one_gpu: the ranks share cuda:0 over gloo).  Every rank decodes only
+    its own image shard, the ring carries the ViT taps, rank 0 writes the pickles: equal, bit for bit, to those of the
+    plain one-process run."""
+    import socket
+    import subprocess
+    import sys
+    main, test_mod = _load_examples()
+    argv = ["--dataset", "synthetic", "--categories", "toothbrush", "grid", "--supervised", "both", "--batch_size", "64",
+            "--category_schedule", schedule]
+    ref = main.main(argv + ["--output_dir", str(tmp_path / "one")])
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.path.join(EXAMPLES, "main.py")
+    env = dict(os.environ, AC_BACKBONE_SEED=os.environ.get("AC_BACKBONE_SEED", "0"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), script] + argv +
+                       ["--output_dir", str(tmp_path / "two"), "--rehearse_on_one_gpu"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for (mode, cat), (a, X) in ref.items():
+        f = "/synthetic/dino_vitbase8/%s/blocks.10_blocks.11_2048_4096_1.0_1.0/matrix_alpha_X_%s_%s.pickle" % (mode, cat, mode)
+        saved = test_mod._safe_load(str(tmp_path / "two") + f)
+        assert torch.equal(saved[0], a) and np.array_equal(saved[1], X), (mode, cat)
+    assert len(test_mod._safe_load(str(tmp_path / "two") + "/synthetic/info/info_grid.pickle")) == 78
