@@ -212,13 +212,25 @@ class HipOps:
     def zshape(self):
         """(P, D) of one image's Z."""
         if self._zshape is None:
-            self._probe()
+            probe = torch.ones((1,) + tuple(self.core.input_shape), device=self.core.device)
+            self._zshape = tuple(self.core.embed_device(probe, batch_size=1).shape[1:])
         return self._zshape
 
     def wants_lean(self, n_images):
+        """Lean when Z + packed of n_images would not fit comfortably - and the backbone's taps can be kept at all (token
+        maps; the channels-last views of the CNN branch cannot, and its categories are small)."""
+        if self.core is None:                 # the engine alone (no backbone behind the seam): there are no taps to keep
+            return False
         P, D = self.zshape()
         free, _ = torch.cuda.mem_get_info(self.core.device)
-        return n_images * 2 * P * D * 4 > self.LEAN_FRACTION * free
+        if n_images * 2 * P * D * 4 <= self.LEAN_FRACTION * free:
+            return False
+        if self._tapshapes is None:
+            try:
+                self._probe()
+            except RuntimeError:
+                return False
+        return True
 
     def embed_taps(self, images):
         """Taps of the images, Z never materialised as a whole (25.7 -> 17.7 MB of HBM per image with the packed copy)."""
