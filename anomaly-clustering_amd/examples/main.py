@@ -232,7 +232,9 @@ def build_parser():
                         help="unsupervised | supervised | average | both")
     parser.add_argument('--dataset', default='mvtec_ad', type=str, help="Dataset to use (mvtec_ad | synthetic).")
     parser.add_argument('--categories', nargs='*', default=None, help="Subset of categories (default: all 15).")
-    parser.add_argument('--batch_size', type=int, default=32, help="Images per ViT launch.")
+    parser.add_argument('--batch_size', type=int, default=256,
+                        help="Largest ViT launch, in images (longer streams are cut into launches that fill whole tile "
+                             "rounds of the chip: pipeline.vit_batch_plan).")
     parser.add_argument('--category_schedule', default="pipeline", choices=["pipeline", "sequential", "per_gpu"],
                         help="pipeline: all categories as one job (pipeline.run_categories); sequential: one category "
                              "after another, as the reference loops them; per_gpu: whole categories to GPUs.")

@@ -61,6 +61,20 @@ class PatchMaker:
         return x.numpy() if was_numpy else x
 
 
+def _batch_edges(n, batch_size):
+    """[(first, last)] of the ViT launches over n images: `batch_size` images each, or - when it is a list - exactly those
+    sizes in turn (pipeline.vit_batch_plan: launch sizes whose tile grids fill whole rounds of the chip)."""
+    if isinstance(batch_size, (list, tuple)):
+        if sum(batch_size) != n or any(b <= 0 for b in batch_size):
+            raise ValueError("batch plan %r does not cover %d images" % (list(batch_size), n))
+        edges, s0 = [], 0
+        for b in batch_size:
+            edges.append((s0, s0 + b))
+            s0 += b
+        return edges
+    return [(s0, min(n, s0 + batch_size)) for s0 in range(0, n, batch_size)]
+
+
 class AnomalyClusteringCore(torch.nn.Module):
     def __init__(self, device):
         super().__init__()
@@ -120,9 +134,10 @@ class AnomalyClusteringCore(torch.nn.Module):
         once and every batch's aggregation kernel writes its rows in place (no concatenation copy)."""
         N = images.shape[0]
         dims = getattr(self, "_zdims", None)
-        Z = torch.empty((N,) + dims, dtype=torch.float32, device=self.device) if (dims and N > batch_size) else None
-        for s in range(0, N, batch_size):
-            chunk = images[s:s + batch_size].to(self.device, dtype=torch.float32, non_blocking=True)
+        edges = _batch_edges(N, batch_size)
+        Z = torch.empty((N,) + dims, dtype=torch.float32, device=self.device) if (dims and len(edges) > 1) else None
+        for s, e in edges:
+            chunk = images[s:e].to(self.device, dtype=torch.float32, non_blocking=True)
             if Z is None:
                 z = self._embed(chunk, None, detach=False)
                 rows = z.shape[0] // chunk.shape[0]
@@ -154,8 +169,8 @@ class AnomalyClusteringCore(torch.nn.Module):
         N = images.shape[0]
         bufs = None
         _ = self.forward_modules["feature_aggregator"].eval()
-        for s in range(0, N, batch_size):
-            chunk = images[s:s + batch_size].to(self.device, dtype=torch.float32, non_blocking=True)
+        for s, e in _batch_edges(N, batch_size):
+            chunk = images[s:e].to(self.device, dtype=torch.float32, non_blocking=True)
             taps = self.forward_modules["feature_aggregator"](chunk)
             feats = [taps[layer] for layer in self.layers_to_extract_from]
             if not all(t.is_contiguous() for t in feats):
@@ -191,8 +206,9 @@ class AnomalyClusteringCore(torch.nn.Module):
         starts = [0]
         for c in counts:
             starts.append(starts[-1] + c)
-        for s in range(0, total, batch_size):
-            e = min(total, s + batch_size)
+        edges = _batch_edges(total, batch_size)
+        largest = max(e - s for s, e in edges)
+        for s, e in edges:
             segs = [(i, max(s, starts[i]) - starts[i], min(e, starts[i + 1]) - starts[i])
                     for i in range(len(counts)) if starts[i] < e and starts[i + 1] > s]
             if len(segs) == 1:
@@ -200,7 +216,7 @@ class AnomalyClusteringCore(torch.nn.Module):
                 chunk = image_sets[i][a:b].to(self.device, dtype=torch.float32, non_blocking=True)
             else:
                 if stage is None:
-                    stage = torch.empty((batch_size,) + shape, dtype=torch.float32, device=self.device)
+                    stage = torch.empty((largest,) + shape, dtype=torch.float32, device=self.device)
                 off = 0
                 for i, a, b in segs:
                     stage[off: off + (b - a)].copy_(image_sets[i][a:b], non_blocking=True)

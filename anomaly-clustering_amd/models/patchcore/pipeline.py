@@ -119,6 +119,73 @@ def unsup_schedule(bounds, rank, c):
                 yield ("two", k, a, b)
 
 
+# ------------------------------------------------------------------ ViT launch sizes by whole rounds of the chip
+VIT_TILE_ROWS = 256            # row tile of the linear-layer kernels (csrc/gemm_hl5.h)
+VIT_TAIL_WEIGHT = 0.18         # what an unfilled last round costs, as a share of a full one (measured: profiles/r04_vit_batch_sweep.txt)
+VIT_LAUNCH_IMAGES = 1.5        # fixed cost of one ViT launch sequence, in images
+
+
+def _vit_rounds(b, tokens, embed_dim, cus):
+    """Tile rounds of the narrowest linear layer (proj / fc2: embed_dim columns) of a launch on b images; the wider layers
+    (qkv: 3x, fc1: 4x the column tiles) fill whole rounds whenever this one does."""
+    return -(-b * tokens // VIT_TILE_ROWS) * -(-embed_dim // 256) / float(cus)
+
+
+def vit_batch_cost(b, tokens, embed_dim, cus=256):
+    """Relative cost (in images) of one ViT launch on b images: b, plus the idle share of the last tile round.  A launch on
+    84 images needs 9.07 rounds of 256 tiles for qkv (3.02 for proj): the chip waits for the 0.07 - measured +5.3 % per
+    image against 83 images (8.96 rounds); 111 / 138 / 166 / 194 / 222 / 250 images sit just below whole rounds, too."""
+    if b <= 0:
+        return 0.0
+    r = _vit_rounds(b, tokens, embed_dim, cus)
+    idle = math.ceil(r - 1e-9) - r
+    return b * (1.0 + VIT_TAIL_WEIGHT * max(idle, 0.0) / r) + VIT_LAUNCH_IMAGES
+
+
+def vit_batch_plan(total, limit, tokens, embed_dim, cus=256):
+    """Sizes of the ViT launches over `total` images, none above `limit`: launches that fill whole tile rounds of the chip
+    (the largest such size <= limit, and smaller ones where they save a ragged remainder), the one remainder last.  An
+    image's embedding does not depend on its batch (tests: bitwise), so this only moves time: 1725 images in launches of
+    128 cost 445 us per image, in launches of 250 / 222 / ... 431."""
+    total, limit = int(total), max(1, int(limit))
+    if total <= limit:
+        return [total] if total else []
+    good = []
+    k = 1
+    while True:
+        b = (cus * k // -(-embed_dim // 256)) * VIT_TILE_ROWS // tokens     # largest b with rounds(b) <= k
+        if b > limit:
+            break
+        if b >= 1 and (not good or b != good[-1]):
+            good.append(b)
+        k += 1
+    if not good:
+        good = [limit]
+    cost = {g: vit_batch_cost(g, tokens, embed_dim, cus) for g in good}
+    INF = float("inf")
+    best, take = [0.0] + [INF] * total, [0] * (total + 1)       # launches of good sizes only (unbounded knapsack)
+    for t in range(1, total + 1):
+        for g in good:
+            if g <= t and best[t - g] + cost[g] < best[t]:
+                best[t], take[t] = best[t - g] + cost[g], g
+    pick, rest = None, 0
+    for r in range(0, limit + 1):                               # ... plus ONE launch of any size
+        if r <= total and best[total - r] < INF:
+            c = best[total - r] + vit_batch_cost(r, tokens, embed_dim, cus)
+            if pick is None or c < pick:
+                pick, rest = c, r
+    plan, t = [], total - rest
+    while t > 0:
+        plan.append(take[t])
+        t -= take[t]
+    plan.sort(reverse=True)
+    plan += [rest] if rest else []
+    naive = [limit] * (total // limit) + ([total % limit] if total % limit else [])
+    if sum(vit_batch_cost(b, tokens, embed_dim, cus) for b in naive) < pick:      # never worse than plain batches of `limit`
+        return naive
+    return plan
+
+
 class Taps:
     """The tapped feature maps of a block of images ([n, 785, 768] x 2 for ViT-B/8: 4.8 MB per image) - what goes round
     the ring instead of the packed embeddings (12.85 MB per image): the receiver runs the aggregation kernel on them
@@ -152,12 +219,27 @@ class HipOps:
         import acnative
         self.acnative = acnative
         self.core = core
-        self.batch_size = batch_size
+        self.batch_size = batch_size          # the LARGEST ViT launch; the sizes actually used: batches()
         self._zshape = None
         self._tapshapes = None
+        self._plans = {}
         # what a multi-rank run sends round the ring: the taps (2.7x fewer bytes) when there is a backbone to tap
         # (AC_RING_PAYLOAD=packed keeps the packed shards selectable: A/B on the first multi-GPU node)
         self.ring_payload = "taps" if (core is not None and os.environ.get("AC_RING_PAYLOAD", "taps") == "taps") else None
+
+    def batches(self, total):
+        """The launch sizes over `total` images: for a token backbone (ViT) those that fill whole tile rounds of the chip
+        (vit_batch_plan); otherwise plain batches of batch_size."""
+        bb = getattr(self.core, "backbone", None)
+        tokens = getattr(getattr(bb, "patch_embed", None), "num_patches", None)
+        dim = getattr(bb, "embed_dim", None)
+        if not tokens or not dim or total <= self.batch_size or os.environ.get("AC_VIT_BATCH_PLAN") == "naive":
+            return self.batch_size                      # (AC_VIT_BATCH_PLAN=naive: plain batches, for a same-box A/B)
+        cus = torch.cuda.get_device_properties(self.core.device).multi_processor_count
+        key = (int(total), self.batch_size, tokens, dim, cus)
+        if key not in self._plans:
+            self._plans[key] = vit_batch_plan(total, self.batch_size, tokens + 1, dim, cus)
+        return self._plans[key]
 
     def _probe(self):
         probe = torch.ones((1,) + tuple(self.core.input_shape), device=self.core.device)
@@ -180,7 +262,7 @@ class HipOps:
         if want_taps:
             Zs, taps = self.embed_many([images], want_taps=True)
             return Zs[0], taps[0]
-        Z = self.core.embed_device(images, batch_size=self.batch_size)
+        Z = self.core.embed_device(images, batch_size=self.batches(images.shape[0]))
         self._zshape = tuple(Z.shape[1:])
         return Z
 
@@ -191,7 +273,8 @@ class HipOps:
         if sum(int(s.shape[0]) for s in image_sets) == 0:
             res = [self._empty(want_taps) for _ in image_sets]
             return ([r[0] for r in res], [r[1] for r in res]) if want_taps else res
-        out = self.core.embed_device_many(image_sets, batch_size=self.batch_size, want_taps=want_taps)
+        out = self.core.embed_device_many(image_sets, batch_size=self.batches(sum(int(x.shape[0]) for x in image_sets)),
+                                          want_taps=want_taps)
         Zs = out[0] if want_taps else out
         self._zshape = tuple(Zs[0].shape[1:])
         if want_taps:
@@ -236,7 +319,7 @@ class HipOps:
         """Taps of the images, Z never materialised as a whole (25.7 -> 17.7 MB of HBM per image with the packed copy)."""
         if images.shape[0] == 0:
             return self._empty(True)[1]
-        feats = self.core.embed_taps_device(images, batch_size=self.batch_size)
+        feats = self.core.embed_taps_device(images, batch_size=self.batches(images.shape[0]))
         self._tapshapes = [(tuple(t.shape[1:]), t.dtype) for t in feats]
         return Taps(feats, int(images.shape[0]))
 

@@ -63,7 +63,9 @@ def parse():
     ap.add_argument("--config", default="2", choices=CONFIGS)
     ap.add_argument("--category", default=None, help="config 2 only: another MVTec-AD category shape")
     ap.add_argument("--n", type=int, default=10000, help="config 5: images in the synthetic category")
-    ap.add_argument("--batch", type=int, default=128, help="images per ViT launch")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="largest ViT launch, in images; a longer stream is cut into launches that fill whole tile rounds of the "
+                         "chip (pipeline.vit_batch_plan: 250 / 222 / 194 / ... images for ViT-B/8 on 256 CUs)")
     ap.add_argument("--tau", type=float, default=1.0)
     ap.add_argument("--budget-mb", type=int, default=1024, help="memory budget of one matrix of minima")
     ap.add_argument("--schedule", default="auto", choices=["auto", "slices", "ring"])
