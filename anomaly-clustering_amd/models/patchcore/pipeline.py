@@ -337,6 +337,8 @@ class HipOps:
         """X = alpha . Z with Z rebuilt from the taps chunk by chunk (main.py:292-296 on a category whose Z was dropped)."""
         P, D = self.zshape()
         X = torch.empty((taps.n, D), dtype=torch.float32, device=taps.device)
+        if taps.n == 0:                                        # a rank with an empty image shard
+            return X
         alpha_f32 = alpha_f32.reshape(taps.n, -1)
         for s in range(0, taps.n, self.LEAN_CHUNK):
             e = min(taps.n, s + self.LEAN_CHUNK)
