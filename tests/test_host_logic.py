@@ -344,3 +344,14 @@ def test_vit_batch_plan_fills_whole_tile_rounds():
     # other widths / chips: ViT-S (one column tile of 384 -> 2), 304 CUs
     plan = vit_batch_plan(1000, 200, 197, 384, 304)
     assert sum(plan) == 1000 and max(plan) <= 200
+
+
+def test_batch_edges_follow_a_plan_or_a_size():
+    from patchcore.patchcore import _batch_edges
+    assert _batch_edges(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert _batch_edges(10, [3, 3, 4]) == [(0, 3), (3, 6), (6, 10)]
+    assert _batch_edges(0, 4) == [] and _batch_edges(5, 8) == [(0, 5)]
+    with pytest.raises(ValueError):
+        _batch_edges(10, [3, 3])                          # a plan must cover every image
+    with pytest.raises(ValueError):
+        _batch_edges(3, [3, 0])
