@@ -36,6 +36,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=83)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--slack-scale", type=float, default=1.0,
+                    help="multiply the candidate window by this (what a tighter proven bound would give: timing only, "
+                         "the result is then no longer guaranteed)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -61,6 +64,7 @@ def main():
     qhl, qsq, qh, qmx = packed(1)
     slack = torch.empty(3, device=dev)
     assert l0.ac_nn_slack(kmx.data_ptr(), qmx.data_ptr(), slack.data_ptr(), st) == 0
+    slack[:2] *= a.slack_scale
     rows = n * P
     amin = torch.empty(rows, dtype=torch.int32, device=dev)
     best = torch.empty(rows, dtype=torch.float64, device=dev)
