@@ -34,8 +34,11 @@ def main():
     ap.add_argument("--n", type=int, default=83)
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--more", action="store_true", help="also the ViT forward and the vendor library's fp16 GEMM")
+    ap.add_argument("--lib", default=os.path.join(HERE, "..", "anomaly-clustering_amd", "models", "acnative", "libac_hip.so"),
+                    help="another build of the library (e.g. an -DAC_ABLATE variant: where the joules go)")
+    ap.add_argument("--only-real", action="store_true", help="only the all-pairs kernel on real operands")
     a = ap.parse_args()
-    lib = c.CDLL(os.path.join(HERE, "..", "anomaly-clustering_amd", "models", "acnative", "libac_hip.so"))
+    lib = c.CDLL(a.lib)
     vp, i64, i = c.c_void_p, c.c_int64, c.c_int
     lib.ac_pack_hl32.argtypes = [vp, i64, i, i64, vp, vp, vp]
     lib.ac_fill_u32.argtypes = [vp, i64, c.c_uint32, vp]
@@ -57,6 +60,8 @@ def main():
         return lambda: lib.ac_pair_min_sq_packed(h.data_ptr(), sq.data_ptr(), n, h.data_ptr(), sq.data_ptr(), n, P, D, mb.data_ptr(),
                                                  None, 0, 1, st)
     jobs = [("all-pairs kernel, real operands", pair(hl)), ("all-pairs kernel, zeroed operands", pair(zeros))]
+    if a.only_real:
+        jobs = jobs[:1]
     if a.more:
         import sys
         sys.path.insert(0, os.path.join(HERE, "..", "anomaly-clustering_amd", "models"))
