@@ -3,6 +3,7 @@
 // Reference arithmetic: models/patchcore/utils.py:222-277, examples/main.py:294-296,
 // scipy pdist under examples/test.py:193-195.
 #include "gemm_hl5.h"
+#include "gemm_hl7.h"
 #ifdef AC_EXPERIMENTAL
 #include "experimental/gemm_hl1.h"
 #include "experimental/gemm_hl3.h"
@@ -59,6 +60,7 @@ extern "C" int ac_pack_hl32(const float* src, int64_t rows, int K, int64_t src_l
 // atomicMin per (key image, query column) into minbuf[key_image][query] (d2 >= 0, so the
 // IEEE bit pattern orders like an unsigned integer).
 struct EpiPairMin {
+  using Frag16 = gemm::FragT<16>;
   const float* key_sq;   // [M]  squared norms of the A rows
   const float* qry_sq;   // [N]  squared norms of the B rows
   unsigned* minbuf;      // [images of A][N]: min over the A patches of one image, per B patch
@@ -66,10 +68,12 @@ struct EpiPairMin {
   int M, N, P;
   // upper_only (diagonal blocks of a symmetric problem): elements with row > column are left out - the
   // mirror element, formed with the lower row as the A operand, stands for both.
+  // n_lim (gemm_hl7.h: a 64 x 32 piece of a 64 x 96 wave block padded to a fragment): columns >= n_lim are not this
+  // fragment's and are left alone.
   template <class F>
-  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane, bool upper_only = false) const {
+  __device__ void operator()(const F& f, int m_wave, int n_wave, int lane, bool upper_only = false, int n_lim = 0x7fffffff) const {
     if (m_wave >= M) return;                      // wave-uniform
-    const int m_end = min(m_wave + 64, M);
+    const int m_end = min(m_wave + 64, M), n_end = min(N, n_lim);
     float ksq[F::NT][F::NR];
 #pragma unroll
     for (int mi = 0; mi < F::NT; ++mi)
@@ -99,7 +103,7 @@ struct EpiPairMin {
             mn = (row >= lo && row < hi) ? fminf(mn, d2[mi][i]) : mn;
           }
         mn = F::min_over_row_groups(mn);
-        if (F::first_row_group(lane) && col < N) atomicMin(minbuf + (size_t)img * N + col, __float_as_uint(mn));
+        if (F::first_row_group(lane) && col < n_end) atomicMin(minbuf + (size_t)img * N + col, __float_as_uint(mn));
       }
     }
   }
@@ -109,8 +113,10 @@ struct EpiPairMin {
   // goes through LDS transposed ([column][row], 65-float pitch), then lane l owns row l and takes the
   // min over the columns of each key image.
   template <class F>
-  __device__ void transposed(const F& f, int m_wave, int n_wave, int lane, float* tb, bool upper_only = false) const {
-    if (m_wave >= M || n_wave >= N) return;       // wave-uniform
+  __device__ void transposed(const F& f, int m_wave, int n_wave, int lane, float* tb, bool upper_only = false,
+                             int n_lim = 0x7fffffff) const {
+    const int n_end = min(N, n_lim);
+    if (m_wave >= M || n_wave >= n_end) return;   // wave-uniform
     float ksq[F::NT][F::NR];
 #pragma unroll
     for (int mi = 0; mi < F::NT; ++mi)
@@ -120,7 +126,7 @@ struct EpiPairMin {
 #pragma unroll
     for (int ni = 0; ni < F::NT; ++ni) {
       const int c_base = n_wave + ni * F::TW;
-      if (c_base >= N) break;                      // wave-uniform
+      if (c_base >= n_end) break;                  // wave-uniform
       const int cl = F::col(ni, lane) - ni * F::TW;
       const float qs = qry_sq[min(c_base + cl, N - 1)];
 #pragma unroll
@@ -133,7 +139,7 @@ struct EpiPairMin {
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      const int c_end = min(c_base + F::TW, N);
+      const int c_end = min(c_base + F::TW, n_end);
       for (int img = c_base / P; img <= (c_end - 1) / P; ++img) {   // wave-uniform, <= 2 trips when P >= 32
         const int lo = max(img * P, c_base) - c_base, hi = min((img + 1) * P, c_end) - c_base;
         float mn = __builtin_inff();
@@ -166,67 +172,82 @@ struct EpiPairMin {
   template <class F>
   __device__ bool fast(F& f, int m_wave, int n_wave, int lane, bool both_ways) const {
     static_assert(F::TW == 16 && F::NT == 4 && F::NR == 4, "written for the 16x16x32 accumulator layout");
+    return fast_wide<4>(f.acc, m_wave, n_wave, lane, both_ways);
+  }
+  // NTN column tiles of 16: the 64 x 64 wave block of gemm_hl2.h (NTN = 4) and the 64 x 96 block of gemm_hl7.h (6).
+  template <int NTN>
+  __device__ bool fast_wide(f32x4 (&acc)[4][NTN], int m_wave, int n_wave, int lane, bool both_ways) const {
+    static_assert(NTN >= 4 && NTN <= 8, "direction 1 keeps its columns in two atomicMin wave-instructions");
+    constexpr int W = 16 * NTN;
 #ifdef AC_NO_FAST_EPI                        // diagnostic builds: the general epilogue everywhere (same-box A/B)
     return false;
 #endif
-    if (m_wave + 64 > M || n_wave + 64 > N || P < 64 || (reinterpret_cast<uintptr_t>(key_sq) & 15)) return false;
+    if (m_wave + 64 > M || n_wave + W > N || P < W || (reinterpret_cast<uintptr_t>(key_sq) & 15)) return false;
     const int g = lane >> 4, c = lane & 15;
     f32x4 ks[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(key_sq + m_wave + 16 * mi + 4 * g);
-    float qs[4];
+    float qs[NTN];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) qs[ni] = qry_sq[n_wave + 16 * ni + c];
+    for (int ni = 0; ni < NTN; ++ni) qs[ni] = qry_sq[n_wave + 16 * ni + c];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NTN; ++ni)
 #pragma unroll
         for (int i = 0; i < 4; ++i)      // (|k|^2 - k.q) + (|q|^2 - k.q): both differences are small before they meet
-          f.acc[mi][ni][i] = fmaxf((ks[mi][i] - f.acc[mi][ni][i]) + (qs[ni] - f.acc[mi][ni][i]), 0.f);
+          acc[mi][ni][i] = fmaxf((ks[mi][i] - acc[mi][ni][i]) + (qs[ni] - acc[mi][ni][i]), 0.f);
     const float inf = __builtin_inff();
 
     // ---- direction 1: rows are key patches of image r_img (and r_img + 1 from local row br on)
     const int r_img = m_wave / P;
     const int br = (r_img + 1) * P - m_wave;            // first local row of the next image; >= 64: no boundary inside
     {
-      float mn0[4], mn1[4];
+      float mn0[NTN], mn1[NTN];
       if (br >= 64) {                                   // wave-uniform
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NTN; ++ni) {
           float m = inf;
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m = fminf(m, f.acc[mi][ni][i]);
+            for (int i = 0; i < 4; ++i) m = fminf(m, acc[mi][ni][i]);
           mn0[ni] = m;
         }
       } else {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { mn0[ni] = inf; mn1[ni] = inf; }
+        for (int ni = 0; ni < NTN; ++ni) { mn0[ni] = inf; mn1[ni] = inf; }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const bool first = 16 * mi + 4 * g + i < br;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              const float v = f.acc[mi][ni][i];
+            for (int ni = 0; ni < NTN; ++ni) {
+              const float v = acc[mi][ni][i];
               mn0[ni] = fminf(mn0[ni], first ? v : inf);
               mn1[ni] = fminf(mn1[ni], first ? inf : v);
             }
           }
       }
-      float v0 = inf, v1 = inf;
+      // lane (g, c) owns column 16 g + c = lane of the first 64 columns, and column 64 + lane of the rest (lanes < W - 64)
+      float v0 = inf, v1 = inf, u0 = inf, u1 = inf;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        float m = F::min_over_row_groups(mn0[ni]);      // valid in every lane of the column
-        v0 = (g == ni) ? m : v0;
-        if (br < 64) { m = F::min_over_row_groups(mn1[ni]); v1 = (g == ni) ? m : v1; }
+      for (int ni = 0; ni < NTN; ++ni) {
+        float m = Frag16::min_over_row_groups(mn0[ni]);      // valid in every lane of the column
+        if (ni < 4) v0 = (g == ni) ? m : v0; else u0 = (g == ni - 4) ? m : u0;
+        if (br < 64) {
+          m = Frag16::min_over_row_groups(mn1[ni]);
+          if (ni < 4) v1 = (g == ni) ? m : v1; else u1 = (g == ni - 4) ? m : u1;
+        }
       }
-      unsigned* dst = minbuf + (size_t)r_img * N + n_wave + lane;    // lane (g, c) owns column 16 g + c = lane
+      unsigned* dst = minbuf + (size_t)r_img * N + n_wave + lane;
       atomicMin(dst, __float_as_uint(v0));
       if (br < 64) atomicMin(dst + N, __float_as_uint(v1));
+      if (NTN > 4 && lane < W - 64) {
+        atomicMin(dst + 64, __float_as_uint(u0));
+        if (br < 64) atomicMin(dst + N + 64, __float_as_uint(u1));
+      }
     }
     if (!both_ways) return true;
 
@@ -235,24 +256,28 @@ struct EpiPairMin {
     const int bc = (c_img + 1) * P - n_wave;
     {
       float t0[4][4], t1[4][4];
-      if (bc >= 64) {
+      if (bc >= W) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            t0[mi][i] = fminf(fminf(f.acc[mi][0][i], f.acc[mi][1][i]), fminf(f.acc[mi][2][i], f.acc[mi][3][i]));
-      } else {
-        bool first[4];
+          for (int i = 0; i < 4; ++i) {
+            float m = fminf(fminf(acc[mi][0][i], acc[mi][1][i]), fminf(acc[mi][2][i], acc[mi][3][i]));
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) first[ni] = 16 * ni + c < bc;
+            for (int ni = 4; ni < NTN; ++ni) m = fminf(m, acc[mi][ni][i]);
+            t0[mi][i] = m;
+          }
+      } else {
+        bool first[NTN];
+#pragma unroll
+        for (int ni = 0; ni < NTN; ++ni) first[ni] = 16 * ni + c < bc;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float a = inf, b = inf;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              const float v = f.acc[mi][ni][i];
+            for (int ni = 0; ni < NTN; ++ni) {
+              const float v = acc[mi][ni][i];
               a = fminf(a, first[ni] ? v : inf);
               b = fminf(b, first[ni] ? inf : v);
             }
@@ -268,7 +293,7 @@ struct EpiPairMin {
           float m = t0[mi][i];
           m = fminf(m, row_ror<8>(m)); m = fminf(m, row_ror<4>(m)); m = fminf(m, row_ror<2>(m)); m = fminf(m, row_ror<1>(m));
           v0 = (c == 4 * mi + i) ? m : v0;
-          if (bc < 64) {
+          if (bc < W) {
             m = t1[mi][i];
             m = fminf(m, row_ror<8>(m)); m = fminf(m, row_ror<4>(m)); m = fminf(m, row_ror<2>(m)); m = fminf(m, row_ror<1>(m));
             v1 = (c == 4 * mi + i) ? m : v1;
@@ -277,7 +302,7 @@ struct EpiPairMin {
       // lane (g, c) owns local row 16 (c >> 2) + 4 g + (c & 3): the wave's 64 rows, each once
       unsigned* dst = minbuf_t + (size_t)c_img * M + m_wave + 16 * (c >> 2) + 4 * g + (c & 3);
       atomicMin(dst, __float_as_uint(v0));
-      if (bc < 64) atomicMin(dst + M, __float_as_uint(v1));
+      if (bc < W) atomicMin(dst + M, __float_as_uint(v1));
     }
     return true;
   }
@@ -311,6 +336,13 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
 #ifndef AC_PAIR_DYNAMIC
 #define AC_PAIR_DYNAMIC 1           // dynamic tile queues for launches of >= 4 tiles per CU (gemm_hl2.h); 0: A/B builds
 #endif
+  // Round 5: the 256x192 tile (gemm_hl7.h) unless the 256x128 kernel is pinned (ac_set_gemm_policy(AC_GEMM_256x128):
+  // the two agree to the bit, tests/test_gemm_generations_gpu.py; -DAC_PAIR_TILE=128 builds pin it for A/B runs).
+#ifndef AC_PAIR_TILE
+#define AC_PAIR_TILE 192
+#endif
+  if (AC_PAIR_TILE == 192 && ac_gemm_policy() != AC_GEMM_256x128)
+    return gemm7::launch<EpiPairMin>(A, B, M, N, K, epi, stream, group_m, part, nparts, AC_PAIR_DYNAMIC != 0);
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts, false, AC_PAIR_DYNAMIC != 0);
 }
 

@@ -51,11 +51,57 @@ constexpr int FLUSH_STAGES = 16;
 // rasterisation is unchanged - and a workgroup whose own queue is empty steals from the others.  Why: equal tile
 // counts per XCD do not finish together (sampled stamps, profiles/r04_allpairs_tile_timing.txt: the eight XCDs end
 // 1.35 ms apart on a 42 ms launch); stealing evens that out, and the workgroup launch between two tiles goes away.
-// Counters: QUEUE_SLOTS sets of 8 tickets + 1 exit count in device memory, one set per launch in rotation (a set is
-// zero when a launch starts: the last workgroup to leave resets it; two launches share a set only if QUEUE_SLOTS launches
-// are in flight on the device at once).  Every workgroup leaves when all eight queues are exhausted: no spinning.
+// Counters: QUEUE_SLOTS sets of 8 tickets in device memory, one set per launch in rotation; the launcher zeroes the
+// chosen set ON THE LAUNCH STREAM right before the kernel (round 5: a kernel that died can no longer leave stale
+// tickets behind, and nothing depends on the previous user of the set having left cleanly).  Two launches share a set
+// only if QUEUE_SLOTS dynamic launches of this translation unit are in flight on the device at once.  Every workgroup
+// leaves when all eight queues are exhausted: no spinning.
 constexpr int QUEUE_SLOTS = 64, QUEUE_STRIDE = 16;
 static __device__ unsigned g_tile_queues[QUEUE_SLOTS * QUEUE_STRIDE];
+
+// Thread 0 of a workgroup pulls in two steps, so that the ticket's round trip overlaps other memory latency instead of
+// stalling its wave: queue_take() issues the returning atomic on the workgroup's OWN queue; queue_resolve() - later -
+// turns the ticket into a block id and steals from the other queues only when the own one is exhausted (the tail of the
+// launch); -1 = every queue is exhausted.
+// Round 5 (advice on round 4): the atomic is the compiler's own builtin, so hipcc KNOWS the result register is pending and
+// places the s_waitcnt in front of its first use - round 4 issued it from inline assembly, whose output register the
+// compiler was free to copy or spill before the value had arrived.  What keeps the builtin from being rewritten: with a
+// wave-uniform address hipcc's atomic optimiser turns the add into a wave reduction whose v_readfirstlane consumes the
+// result at once (a full memory round trip with wave 0 parked right after the k loop); an opaque zero from a one-line
+// asm makes the address divergent in the compiler's eyes and the add stays one global_atomic_add_u32 ... sc0.
+__device__ inline unsigned queue_take(unsigned* queue) {
+  unsigned zero;
+  asm("v_mov_b32 %0, 0" : "=v"(zero));
+  return __hip_atomic_fetch_add(queue + (blockIdx.x & 7) + zero, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int queue_resolve(unsigned* queue, unsigned ticket, int id_lo, int id_hi) {
+  const int x = blockIdx.x & 7;
+  long long cand = (long long)id_lo + 8ll * ticket + x;
+  int got = cand < id_hi ? (int)cand : -1;
+  for (int j = 1; j < 8 && got < 0; ++j) {
+    const int y = (x + j) & 7;
+    cand = (long long)id_lo + 8ll * atomicAdd(queue + y, 1u) + y;
+    if (cand < id_hi) got = (int)cand;
+  }
+  return got;
+}
+// Host side: the next counter set of THIS translation unit in rotation, zeroed on the launch stream.
+static inline int queue_acquire(unsigned** queue, hipStream_t stream) {
+  static unsigned next_slot = 0;                 // one per translation unit, next to its g_tile_queues
+  static void* base_of[64] = {};                 // per device: the address of this module's counters there
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ac_fail(AC_ELAUNCH, "tile queues: hipGetDevice failed");
+  void* base = __atomic_load_n(&base_of[dev], __ATOMIC_RELAXED);
+  if (!base) {
+    if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_tile_queues)) != hipSuccess || !base)
+      return ac_fail(AC_ELAUNCH, "tile queues: hipGetSymbolAddress(g_tile_queues) failed");
+    __atomic_store_n(&base_of[dev], base, __ATOMIC_RELAXED);
+  }
+  const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % QUEUE_SLOTS;
+  *queue = static_cast<unsigned*>(base) + slot * QUEUE_STRIDE;
+  if (hipMemsetAsync(*queue, 0, 8 * sizeof(unsigned), stream) != hipSuccess) return ac_fail(AC_ELAUNCH, "tile queues: hipMemsetAsync failed");
+  return AC_OK;
+}
 
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE=1 no DMA issue in the loop, 2 no
 // fragment reads after stage 0, 4 no MFMAs (combinable).  0 in every shipped build.
@@ -220,36 +266,8 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   // dynamic walk (queue != nullptr): thread 0 pulls the next block id - own queue first, then the others' - and hands it
   // to the workgroup through LDS; -1 = every queue is exhausted
   int* const lds_next = reinterpret_cast<int*>(smem + LDS_BYTES);
-  // Two steps, so that the ticket's round trip overlaps other memory latency instead of stalling wave 0: take() issues
-  // the atomic on the workgroup's OWN queue (the returned value is not touched yet); resolve() - later - turns it into a
-  // block id, steals from the other queues only when the own one is exhausted (the tail of the launch), and publishes.
-  // (take() is inline assembly: hipcc's atomic optimiser rewrites an atomicAdd in divergent code into a wave reduction
-  // whose v_readfirstlane consumes the result at once - a full memory round trip with wave 0 parked right after the k
-  // loop.  The compiler's own vmcnt bookkeeping stays correct with one more, OLDER operation in flight: counted waits
-  // can only become stricter.)
-  auto take = [&]() -> unsigned {                  // thread 0 only
-    unsigned ticket;
-    unsigned* addr = queue + (blockIdx.x & 7);
-    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(addr), "v"(1u) : "memory");
-    return ticket;
-  };
-  auto resolve = [&](unsigned ticket) {            // thread 0 only
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");   // the ticket has arrived
-    const int x = blockIdx.x & 7;
-    long long cand = (long long)id_lo + 8ll * ticket + x;
-    int got = cand < id_hi ? (int)cand : -1;
-    for (int j = 1; j < 8 && got < 0; ++j) {
-      const int y = (x + j) & 7;
-      cand = (long long)id_lo + 8ll * atomicAdd(queue + y, 1u) + y;
-      if (cand < id_hi) got = (int)cand;
-    }
-    *lds_next = got;
-  };
-  auto leave = [&]() {                             // thread 0 only: the last workgroup out zeroes the counters
-    if (atomicAdd(queue + 8, 1u) == gridDim.x - 1) {
-      for (int j = 0; j < 9; ++j) atomicExch(queue + j, 0u);
-    }
-  };
+  auto take = [&]() -> unsigned { return queue_take(queue); };                                        // thread 0 only
+  auto resolve = [&](unsigned ticket) { *lds_next = queue_resolve(queue, ticket, id_lo, id_hi); };   // thread 0 only
 
   // first tile of this workgroup
   int id;
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     __syncthreads();
     id = *lds_next;
     __syncthreads();                               // everyone has read it before thread 0 may overwrite it
-    if (id < 0) { if (tid == 0) leave(); return; }
+    if (id < 0) return;
     setup(id);
   } else {
     id = id_lo + blockIdx.x;
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       next = *lds_next;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       barrier();                                   // ... and has read the ticket before the next pull overwrites it
-      if (next < 0) { if (tid == 0) leave(); break; }
+      if (next < 0) break;
       setup(next);
       issue(0);
       if (nk > 1) issue(1);
@@ -462,18 +480,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   // dynamic walk: worth it (and only meaningful) when every CU gets several tiles
   unsigned* queue = nullptr;
   if (dynamic && hi - lo >= 4ll * n_cu) {
-    static unsigned next_slot = 0;
-    static void* base_of[64] = {};                 // per device: the address of this module's counters there
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ac_fail(AC_ELAUNCH, "gemm_hl2: hipGetDevice failed");
-    void* base = __atomic_load_n(&base_of[dev], __ATOMIC_RELAXED);
-    if (!base) {
-      if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_tile_queues)) != hipSuccess || !base)
-        return ac_fail(AC_ELAUNCH, "gemm_hl2: hipGetSymbolAddress(g_tile_queues) failed");
-      __atomic_store_n(&base_of[dev], base, __ATOMIC_RELAXED);
-    }
-    const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % QUEUE_SLOTS;
-    queue = static_cast<unsigned*>(base) + slot * QUEUE_STRIDE;
+    if (int rc = queue_acquire(&queue, stream)) return rc;
     grid = n_cu;
   }
   int stagger_arg = 0;

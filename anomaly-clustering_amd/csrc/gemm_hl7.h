@@ -1,0 +1,347 @@
+// Split-fp16 MFMA GEMM, 256x192x32 tiles on 8 waves with TWO-LEVEL accumulation: the all-pairs distance kernel (round 5).
+//
+// Why this shape.  The all-pairs kernel needs a second fp32 accumulator per output element (gemm_hl.h: the MFMA
+// accumulator is flushed every 512 k-terms, which is what keeps w at 1.8e-5 from the fp64 truth), so its per-wave state
+// is 2 x (rows x columns / 64) registers and gemm_hl5.h's 256x256 tile (2 x 128) cannot hold it.  gemm_hl2.h's 256x128
+// tile can (2 x 64), at 128 bytes of LDS-DMA and 341 bytes of fragment reads per MFMA - and round 4's power readings
+//  showed that on this chip those BYTES are paid in clock: the DMA stream alone takes the kernel
+// from 2.05 to 1.76 GHz.  256x192 is the largest tile whose two accumulator sets still fit 256 registers:
+//   wave (wm, wn) of a 4 x 2 grid owns 64 rows x 96 columns = 4 x 6 MFMA tiles of 16x16 (v_mfma_f32_16x16x32_f16)
+//   acc 96 + tot 96 registers, the four A (row) fragments of the stage RESIDENT (hi + lo: 32), the B (column) fragment
+//   STREAMED one column step ahead (hi + lo, double buffered: 16)                                   = 240 of 256
+//   -> 99.6 bytes of DMA (-22 %) and 284 bytes of fragment reads (-17 %) per MFMA.
+// (gemm_hl5.h with NT = 6 and its B fragments resident is the same tile at 256 registers + 134 spilled: the loop had to
+// be turned round.)
+//
+// Schedule (gemm_hl5.h's, with the operands' roles exchanged): a wave runs one continuous stream of COLUMN steps (4 row
+// tiles x 3 passes = 12 MFMAs each); the next B fragment is read during the current step, and in the LAST step of a
+// stage every A fragment is re-read for the next stage right after its final MFMA.  LDS 136 KB: A (256 rows, 32 KB per
+// stage) in a 2-slot ring - it goes to registers a stage ahead - and B (192 rows, 24 KB) in a 3-slot ring, filled by
+// global_load_lds from waves 0-3.  ONE barrier per stage t, X(t), before the last column step: everybody's share of
+// A(t+1), B(t+1) has landed; nobody reads B(t) any more and A(t) went to registers a stage ago
+//   -> A(t+2) goes into A(t)'s slot (one stage of cover), B(t+3) into B(t)'s slot (two stages).
+// Tiles: persistent workgroups pull them from gemm_hl2.h's per-XCD-slot queues (dynamic), or one workgroup per tile.
+//
+// Arithmetic: per output element the same chain as gemm_hl2.h's FLUSH kernel - stages in k order, passes hi*lo, lo*hi,
+// hi*hi, the MFMA accumulator added into the second one every 16 stages - so the two kernels agree to the bit
+// (tests/test_gemm_generations_gpu.py, scratch/ab_pairmin.py).
+#pragma once
+#include "gemm_hl2.h"
+
+namespace gemm7 {
+
+using gemm::EpiTraits;
+using gemm2::gptr_t;
+using gemm2::lptr_t;
+using gemm2::tile_off;
+using Frag = gemm::FragT<16>;
+
+constexpr int BM = 256, BN = 192, BK = 32, THREADS = 512;
+constexpr int NTN = 6;                                   // 16-column MFMA tiles per wave (4 row tiles always)
+constexpr int A_HALF = BM * 128, B_HALF = BN * 128;      // 32 KB, 24 KB per stage
+constexpr int A_SLOTS = 2, B_SLOTS = 3;
+constexpr int LDS_BYTES = A_SLOTS * A_HALF + B_SLOTS * B_HALF;   // 136 KB
+constexpr int LDS_EXTRA = 16;                            // the next tile id of a dynamic walk
+constexpr int FLUSH_STAGES = gemm::FLUSH_STAGES;
+
+// Timing-only diagnostic builds (results are wrong): -DAC_ABLATE7=1 no DMA in the k loop, 2 no fragment reads in the
+// k loop, 4 no MFMAs (combinable).  0 in every shipped build.
+#ifndef AC_ABLATE7
+#define AC_ABLATE7 0
+#endif
+
+// ---- upper triangle of a symmetric problem on 256-row x 192-column tiles.  Tile (p, c) holds rows [256 p, +256) and
+// columns [192 c, +192); it contains an element with column >= row iff c >= c0(p) = floor(4 p / 3).
+__host__ __device__ inline int tri_c0(int p) { return (4 * p) / 3; }
+// tiles in the tile rows above p: p Tn - sum_{i < p} floor(4 i / 3); with p = 3 a + b the sum is 6 a^2 - 3 a + 4 a b + [b == 2]
+__host__ __device__ inline long long tri_rows_before(int p, int Tn) {
+  const long long a = p / 3, b = p % 3;
+  return (long long)p * Tn - (6 * a * a - 3 * a + 4 * a * b + (b == 2 ? 1 : 0));
+}
+// Linear order made for the L2, as gemm_hl2.h's: groups of G tile rows; inside a group the ACTUAL column runs slowest
+// and the row fastest, so that a contiguous run of the order (what one XCD works on at a time) covers G row panels and
+// the few column panels they share.
+__device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn) {
+  // row p with F(p) <= lin < F(p + 1), F(p) ~ p Tn - (2/3) p^2
+  const double t = (double)Tn;
+  int p = (int)(0.75 * (t - sqrt(fmax(t * t - (8.0 / 3.0) * (double)lin, 0.0))));
+  p = max(0, min(p, Tm - 1));
+  while (p > 0 && tri_rows_before(p, Tn) > lin) --p;
+  while (p + 1 < Tm && tri_rows_before(p + 1, Tn) <= lin) ++p;
+  const int p0 = (p / G) * G, gsz = min(G, Tm - p0);
+  int w = lin - (int)tri_rows_before(p0, Tn);           // index inside the group
+  int c = tri_c0(p0);
+  const int c_full = tri_c0(p0 + gsz - 1);              // from this column on every row of the group is valid
+  int r = 0;
+  for (;;) {                                            // ragged head: at most 4 (G - 1) / 3 + 1 columns
+    if (c >= c_full) { c = c_full + w / gsz; r = w % gsz; break; }
+    const int v = min(gsz, (3 * c + 2) / 4 - p0 + 1);   // rows p0 .. with c0(row) <= c
+    if (w < v) { r = w; break; }
+    w -= v;
+    ++c;
+  }
+  tm = p0 + r;
+  tn = c;
+}
+
+template <class Epi>
+__device__ inline void tile_of(int id, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
+  if constexpr (EpiTraits<Epi>::kSymmetric) {
+    if (epi.symmetric) {
+      const long long total = tri_rows_before(tiles_m, tiles_n);
+      tri_tile(gemm2::xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m, tm, tn);
+      return;
+    }
+  }
+  gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);
+}
+
+template <class Epi>
+__global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                     int M, int N, int K, int tiles_m, int tiles_n, int group_m,
+                                                     int id_lo, int id_hi, Epi epi, unsigned* queue) {
+  static_assert(!gemm::HasSwap<Epi>::value && EpiTraits<Epi>::kSymmetric, "gemm_hl7 serves the pair-min epilogue");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const Aring = smem;
+  uint8_t* const Bring = smem + A_SLOTS * A_HALF;
+  int* const lds_next = reinterpret_cast<int*>(smem + LDS_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = K / BK;
+  const size_t ld = (size_t)K * 4;
+
+  // DMA map (gemm_hl5.h's): a half-tile is 32 (A) / 24 (B) wave-instructions of 1 KB = 8 rows each, issued by waves
+  // 0-3 only - the SIMD's arbiter serves its older wave first, so their issue stalls hide behind the partner's MFMAs.
+  // Wave w issues rows 32 j + 8 w + (l >> 3); lane l fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of its row.
+  // Registers are what this kernel is short of (240 of 256 hold accumulators and fragments), so the per-lane DMA state
+  // is the lane number alone: row and chunk are rebuilt at every burst, and the lane number is redefined by an empty
+  // asm there - hipcc would otherwise hoist the 14 row offsets of a stage out of the k loop (28 registers, spilled).
+  const bool loader = wave < 4;
+  if (loader) __builtin_amdgcn_s_setprio(2);
+  const unsigned ld32 = (unsigned)K * 4u;
+  int m0 = 0, n0 = 0;
+  auto dma = [&](const uint8_t* src, int first, int last, int t, uint8_t* dst, int pieces) {
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int r = (wave & 3) * 8 + (l >> 3);
+    const uint8_t* base = src + (size_t)t * 128 + (unsigned)((l & 7) ^ ((r >> 1) & 7)) * 16u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= pieces) break;
+      const unsigned row = (unsigned)min(first + r + 32 * j, last);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (uint64_t)row * ld32), (lptr_t)(dst + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
+    }
+  };
+  auto dmaA = [&](int t, int slot) { if (loader) dma(A, m0, M - 1, t, Aring + slot * A_HALF, BM / 32); };
+  auto dmaB = [&](int t, int slot) { if (loader) dma(B, n0, N - 1, t, Bring + slot * B_HALF, BN / 32); };
+  auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+
+  // fragment offsets: 16-row tile t of this wave's rows / columns is base + t * 2048 bytes (the XOR swizzle term
+  // (row >> 1) & 7 is unchanged by +16 rows; 96 wn is a multiple of 16 too); the lo plane of a row is its hi plane's
+  // chunk + 4, i.e. the same offset with bit 6 flipped (slot bases are multiples of 128)
+  const int a_hi = tile_off(wm * 64 + (lane & 15), (lane >> 4));
+  const int b_hi = tile_off(wn * (NTN * 16) + (lane & 15), (lane >> 4));
+  auto frag = [&](int slot_off, int off_hi, int t, half8& hi, half8& lo) {      // slot_off: byte offset of the ring slot in smem
+    const int oh = slot_off + off_hi, ol = oh ^ 64;      // t * 2048 stays an immediate offset of the ds_read
+    lo = *reinterpret_cast<const half8*>(smem + ol + t * 2048);   // lo first: the first pass of a step needs only it
+    hi = *reinterpret_cast<const half8*>(smem + oh + t * 2048);
+  };
+  constexpr int B0 = A_SLOTS * A_HALF;           // the B ring's offset in smem
+
+  // dynamic walk (queue != nullptr): gemm_hl2.h's per-XCD-slot queues with stealing; thread 0 pulls, LDS hands over
+  auto take = [&]() -> unsigned { return gemm2::queue_take(queue); };
+  auto resolve = [&](unsigned ticket) { *lds_next = gemm2::queue_resolve(queue, ticket, id_lo, id_hi); };
+
+  int id, tm = 0, tn = 0;
+  if (queue) {
+    if (tid == 0) resolve(take());
+    __syncthreads();
+    id = *lds_next;
+    __syncthreads();                               // everyone has read it before thread 0 may overwrite it
+    if (id < 0) return;
+  } else {
+    id = id_lo + blockIdx.x;
+    if (id >= id_hi) return;
+  }
+
+  for (;;) {
+    tile_of(id, tiles_m, tiles_n, group_m, epi, tm, tn);          // block-uniform
+    m0 = tm * BM;
+    n0 = tn * BN;
+    f32x4 acc[4][NTN], tot[4][NTN];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NTN; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[mi][ni][i] = 0.f; tot[mi][ni][i] = 0.f; }
+
+    // prologue: A(0) B(0) A(1) B(1) B(2) in that order; the first two must have landed
+    dmaA(0, 0);
+    dmaB(0, 0);
+    if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
+    if (nk > 2) dmaB(2, 2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / 32 + 2 * (BN / 32)) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / 32 + BN / 32) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
+    half8 ah[4], al[4], bh, bl;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) frag(0, a_hi, t, ah[t], al[t]);
+    frag(B0, b_hi, 0, bh, bl);
+
+    int sb = 0;                                    // B slot of the current stage (kt % 3)
+    auto stage = [&](int kt, auto steady) {
+      constexpr bool STEADY = decltype(steady)::value;   // branch-free body while three more stages follow
+      const bool more1 = STEADY || kt + 1 < nk, more2 = STEADY || kt + 2 < nk, more3 = STEADY || kt + 3 < nk;
+      const int sb1 = sb == 2 ? 0 : sb + 1;        // (kt + 1) % 3
+      const int Bs = B0 + sb * B_HALF, Bn = B0 + sb1 * B_HALF, An = ((kt + 1) & 1) * A_HALF;
+      // One column step = three passes over the four row tiles (per element the passes stay in the order hi*lo, lo*hi,
+      // hi*hi).  The lo half of the B fragment is dead after the first pass: the next step's fragment is read right
+      // there - its lo half into the registers just freed, its hi half into the set the step after next will free - and
+      // has the other two passes (8 MFMAs) to arrive.  sched_barrier pins that order: left alone, hipcc sinks the reads
+      // to the end of the step to save registers and waits for them at once.
+#pragma unroll
+      for (int ni = 0; ni < NTN; ++ni) {
+        const bool last = ni == NTN - 1;
+        if (!(AC_ABLATE7 & 4)) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (last && more1) {
+          // own share of A(kt+1), B(kt+1) landed: B(kt+2) (6 instructions, the youngest) may still fly
+          if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BN / 32) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          barrier();                               // X(kt)
+        }
+        half8 nh = bh;
+        if (AC_ABLATE7 & 2) {
+        } else if (!last) {
+          frag(Bs, b_hi, ni + 1, nh, bl);
+        } else if (more1) {
+          frag(Bn, b_hi, 0, nh, bl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (last && more1) {
+          if (more2 && !(AC_ABLATE7 & 1)) dmaA(kt + 2, kt & 1);   // A(kt) went to registers a stage ago
+          if (more3 && !(AC_ABLATE7 & 1)) dmaB(kt + 3, sb);       // nobody reads B(kt) any more
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          if (!(AC_ABLATE7 & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+          if (last && more1 && !(AC_ABLATE7 & 2))
+            al[mi] = *reinterpret_cast<const half8*>(smem + ((An + a_hi) ^ 64) + mi * 2048);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          if (!(AC_ABLATE7 & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+          if (last && more1 && !(AC_ABLATE7 & 2)) ah[mi] = *reinterpret_cast<const half8*>(smem + (An + a_hi) + mi * 2048);
+        }
+        bh = nh;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // Two-level accumulation (gemm_hl.h): flush the MFMA accumulator every 512 k-terms.
+      if ((kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NTN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { tot[mi][ni][i] += acc[mi][ni][i]; acc[mi][ni][i] = 0.f; }
+      }
+      sb = sb1;
+    };
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) stage(kt, std::true_type{});
+    for (; kt < nk; ++kt) stage(kt, std::false_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();                                     // ring reads done: an epilogue / the next prologue may reuse LDS
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NTN; ++ni)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mi][ni][i] += tot[mi][ni][i];
+
+    unsigned ticket = 0;
+    if (queue && tid == 0) ticket = take();        // in flight beside the epilogue's own loads; resolved after it
+
+    // ---- epilogue: the wave's 64 x 96 block at rows m_wave, columns n_wave
+    const int m_wave = m0 + wm * 64, n_wave = n0 + wn * (NTN * 16);
+    const bool sym = epi.symmetric;
+    // symmetric problem: only elements with row <= column are used, each reduced in both directions (gemm_hl2.h).
+    // A block wholly above the diagonal and inside the problem: both reductions from registers (epi.fast_wide);
+    // otherwise the general code on a 64 x 64 and a 64 x 32 piece, per-element diagonal mask where a piece crosses it.
+    const bool below = sym && m_wave > n_wave + (NTN * 16 - 1);
+    if (!below) {
+      const bool both = sym || epi.two_way;
+      const bool clear = !sym || m_wave + 63 <= n_wave;
+      if (!(clear && epi.template fast_wide<NTN>(acc, m_wave, n_wave, lane, both))) {
+        float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+#pragma unroll
+        for (int h = 0; h < (NTN + 3) / 4; ++h) {
+          Frag f;
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) f.acc[mi][ni][i] = (4 * h + ni < NTN) ? acc[mi][(4 * h + ni) % NTN][i] : 0.f;
+          const int n_sub = n_wave + 64 * h, n_lim = n_wave + NTN * 16, width = min(64, NTN * 16 - 64 * h);
+          if (sym && m_wave > n_sub + width - 1) continue;          // this piece lies below the diagonal
+          const bool cross = sym && m_wave + 63 > n_sub;           // some of its elements do
+          epi(f, m_wave, n_sub, lane, cross, n_lim);
+          if (both) epi.transposed(f, m_wave, n_sub, lane, scratch, cross, n_lim);
+        }
+      }
+    }
+
+    if (!queue) break;
+    if (tid == 0) resolve(ticket);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // thread 0's block id is in LDS; everyone is out of the ring
+    barrier();
+    id = *lds_next;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();                                     // ... and has read the id before the next pull overwrites it
+    if (id < 0) break;
+  }
+}
+
+// Host launcher: gemm_hl2.h's contract (M, N arbitrary, K % 32 == 0; part / nparts slices of the tile-id space).
+template <class Epi>
+inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
+                  int group_m = 6, int part = 0, int nparts = 1, bool dynamic = true) {
+  if (M <= 0 || N <= 0) return AC_OK;
+  if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl7: K=%d must be a positive multiple of 32", K);
+  if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl7: bad part %d/%d", part, nparts);
+  if (group_m < 1) return ac_fail(AC_EINVAL, "gemm_hl7: group_m=%d must be positive", group_m);
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  long long total = (long long)tiles_m * tiles_n;
+  if (epi.symmetric) {
+    if (M != N) return ac_fail(AC_EINVAL, "gemm_hl7: symmetric epilogue needs M == N");
+    total = tri_rows_before(tiles_m, tiles_n);
+  }
+  if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl7: grid too large");
+  static unsigned long long attr_done = 0;       // per instantiation, one bit per device
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi>), LDS_BYTES + LDS_EXTRA, &attr_done)) return rc;
+  const long long lo = (total * part / nparts) & ~7LL;
+  const long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
+  if (hi <= lo) return AC_OK;
+  const int n_cu = ac_device_cus();
+  long long grid = hi - lo;
+  unsigned* queue = nullptr;
+  if (dynamic && hi - lo >= 4ll * n_cu) {        // dynamic walk: worth it (and only meaningful) when every CU gets several tiles
+    if (int rc = gemm2::queue_acquire(&queue, stream)) return rc;
+    grid = n_cu;
+  }
+  hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA, stream,
+                     static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
+                     group_m, (int)lo, (int)hi, epi, queue);
+  return ac_check_launch("gemm_hl7");
+}
+
+}  // namespace gemm7
