@@ -174,22 +174,49 @@ struct EpiPairMin {
     static_assert(F::TW == 16 && F::NT == 4 && F::NR == 4, "written for the 16x16x32 accumulator layout");
     return fast_wide<4>(f.acc, m_wave, n_wave, lane, both_ways);
   }
+  // Block-uniform: every 64 x W wave block of the bm x bn tile at (m0, n0) takes fast_wide with both_ways as the kernel
+  // passes it - i.e. no wave of that tile needs LDS in its epilogue (gemm_hl7.h issues the next tile's loads early then).
+  __device__ bool tile_is_fast(int m0, int n0, int bm, int bn, int W) const {
+#ifdef AC_NO_FAST_EPI
+    return false;
+#endif
+    return m0 + bm <= M && n0 + bn <= N && P >= W && !((reinterpret_cast<uintptr_t>(key_sq) | reinterpret_cast<uintptr_t>(qry_sq)) & 15) &&
+           (!symmetric || m0 + bm - 1 <= n0);
+  }
   // NTN column tiles of 16: the 64 x 64 wave block of gemm_hl2.h (NTN = 4) and the 64 x 96 block of gemm_hl7.h (6).
   template <int NTN>
   __device__ bool fast_wide(f32x4 (&acc)[4][NTN], int m_wave, int n_wave, int lane, bool both_ways) const {
+    if (!fast_block<NTN>(m_wave, n_wave)) return false;
+    f32x4 ks[4];
+    float qs[NTN];
+    fast_load<NTN>(m_wave, n_wave, lane, ks, qs);
+    fast_reduce<NTN>(acc, ks, qs, m_wave, n_wave, lane, both_ways);
+    return true;
+  }
+  // The three parts of fast_wide, for a caller that wants the norm loads in flight before other memory traffic of its
+  // own (gemm_hl7.h issues the next tile's first stages between fast_load and fast_reduce).
+  template <int NTN>
+  __device__ bool fast_block(int m_wave, int n_wave) const {            // wave-uniform: does this block qualify?
     static_assert(NTN >= 4 && NTN <= 8, "direction 1 keeps its columns in two atomicMin wave-instructions");
-    constexpr int W = 16 * NTN;
 #ifdef AC_NO_FAST_EPI                        // diagnostic builds: the general epilogue everywhere (same-box A/B)
     return false;
 #endif
-    if (m_wave + 64 > M || n_wave + W > N || P < W || (reinterpret_cast<uintptr_t>(key_sq) & 15)) return false;
+    return !(m_wave + 64 > M || n_wave + 16 * NTN > N || P < 16 * NTN || (reinterpret_cast<uintptr_t>(key_sq) & 15));
+  }
+  template <int NTN>
+  __device__ void fast_load(int m_wave, int n_wave, int lane, f32x4 (&ks)[4], float (&qs)[NTN]) const {
     const int g = lane >> 4, c = lane & 15;
-    f32x4 ks[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(key_sq + m_wave + 16 * mi + 4 * g);
-    float qs[NTN];
 #pragma unroll
     for (int ni = 0; ni < NTN; ++ni) qs[ni] = qry_sq[n_wave + 16 * ni + c];
+  }
+  // returns the number of atomicMin wave-instructions it issued (wave-uniform; 2 ... 6)
+  template <int NTN>
+  __device__ int fast_reduce(f32x4 (&acc)[4][NTN], const f32x4 (&ks)[4], const float (&qs)[NTN], int m_wave, int n_wave,
+                             int lane, bool both_ways) const {
+    constexpr int W = 16 * NTN;
+    const int g = lane >> 4, c = lane & 15;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -249,7 +276,8 @@ struct EpiPairMin {
         if (br < 64) atomicMin(dst + N + 64, __float_as_uint(u1));
       }
     }
-    if (!both_ways) return true;
+    const int n_dir1 = (br < 64 ? 2 : 1) * (NTN > 4 ? 2 : 1);
+    if (!both_ways) return n_dir1;
 
     // ---- direction 2: columns are key patches of image c_img (and c_img + 1 from local column bc on)
     const int c_img = n_wave / P;
@@ -304,7 +332,7 @@ struct EpiPairMin {
       atomicMin(dst, __float_as_uint(v0));
       if (bc < W) atomicMin(dst + M, __float_as_uint(v1));
     }
-    return true;
+    return n_dir1 + (bc < W ? 2 : 1);
   }
   bool symmetric;        // A == B: only the upper triangle of tiles runs, each reduced both ways into minbuf
   bool two_way;          // A != B, both directions wanted: every tile of the rectangle is reduced both ways
@@ -909,14 +937,18 @@ __global__ __launch_bounds__(256) void alpha_softmax_kernel(const float* __restr
   }
 }
 
-extern "C" int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, float* alpha_f32,
-                                void* stream) {
+extern "C" int ac_alpha_softmax_f32(const float* w, int64_t N, int P, double tau, double k, double* alpha, float* alpha_f32,
+                                    void* stream) {
   AC_REQUIRE(w && alpha, "ac_alpha_softmax: null pointer");
   AC_REQUIRE(P > 0 && N >= 0 && N <= 0x7fffffff, "ac_alpha_softmax: bad shape N=%lld P=%d", (long long)N, P);
   AC_REQUIRE(tau >= 0.0, "ac_alpha_softmax: tau=%g must be >= 0", tau);
   if (N == 0) return AC_OK;
   hipLaunchKernelGGL(alpha_softmax_kernel, dim3((unsigned)N), dim3(256), 0, as_stream(stream), w, P, tau, k, alpha, alpha_f32);
   return ac_check_launch("alpha_softmax");
+}
+
+extern "C" int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, void* stream) {
+  return ac_alpha_softmax_f32(w, N, P, tau, k, alpha, nullptr, stream);
 }
 
 // --------------------------------------------------------- weighted average
@@ -1062,6 +1094,16 @@ extern "C" int ac_pdist(const float* X, int64_t N, int D, double* out, void* str
   hipLaunchKernelGGL(pdist_kernel, dim3(t, t), dim3(256), 0, as_stream(stream), X, N, D, out);
   return ac_check_launch("pdist");
 }
+
+#ifdef AC_G7_TIMING
+// Diagnostic builds only (gemm_hl7.h): per persistent workgroup, waves 0 and 4: [tiles, prologue, k loop, vmcnt wait at X,
+// lgkmcnt + barrier wait at X, epilogue + next tile id, whole kernel, stages per tile] in shader-clock cycles.
+extern "C" int ac_debug_wait_times7(unsigned long long* out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm7::ac_wait_times7), sizeof(gemm7::ac_wait_times7)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 #ifdef AC_TILE_TIMING
 // Diagnostic builds only (gemm_hl5.h): per-workgroup [k-loop cycles, X wait, Y wait, stages] of the last

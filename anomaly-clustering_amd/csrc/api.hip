@@ -18,7 +18,7 @@ int ac_check_launch(const char* what) {
 }
 
 extern "C" const char* ac_last_error(void) { return g_err; }
-extern "C" int ac_version(void) { return 300; }   // round 3
+extern "C" int ac_version(void) { return AC_ABI_VERSION; }
 
 // ---- per-device state.  The library keeps no data between calls; what it caches is keyed by the device the
 // calling thread has current, so one process may drive several GPUs (one at a time per call).

@@ -44,14 +44,38 @@ struct Arena {
 //   hi at row*K*4 + (k/32)*128 + (k%32)*2 ; lo at +64.
 __host__ __device__ inline size_t hl32_row_bytes(int K) { return (size_t)K * 4; }
 
+// hi = fp16(x), lo = fp16(x - hi) for TWO values, packed as the MFMA operands want them (x0 in the low half): three
+// vector instructions - one v_cvt_pk_f16_f32 and two v_fma_mix{lo,hi}_f16, which read the fp16 hi half in place
+// (op_sel_hi), form hi * (-1) + x in fp32 and round ONCE to fp16.  x - float(hi) is exact in fp32 (hi is x rounded to 11
+// bits), so the bits equal `(_Float16)(x - (float)hi)`: that form compiles to 2 x v_cvt_f32_f16 + v_pk_add_f32 +
+// v_cvt_pk_f16_f32 per pair, 2.5 instructions per element against 1.5 here - and the split sits in every epilogue that
+// writes hl32, in LayerNorm, in the pack kernel and, per score, in the attention loop, whose vector issue is as busy as
+// its MFMA pipe (round 5; hipcc folds fma(h, -1, x) back into x - h, hence the two lines of assembly).
+__device__ inline void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  const half2_t h = {(_Float16)x0, (_Float16)x1};
+  hi = __builtin_bit_cast(uint32_t, h);
+#ifdef AC_OLD_SPLIT                    // same-box A/B builds: the plain form (scratch/ab_vit.py)
+  const half2_t l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+  lo = __builtin_bit_cast(uint32_t, l);
+  return;
+#endif
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+}
+
 // Split 8 consecutive floats (k % 8 == 0) into the hi / lo fp16 vectors of hl32.
 __device__ inline void split8(const float* v, half8& hi, half8& lo) {
+  u32x4 h, l;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    _Float16 h = (_Float16)v[j];
-    hi[j] = h;
-    lo[j] = (_Float16)(v[j] - (float)h);
+  for (int j = 0; j < 4; ++j) {
+    uint32_t a, b;
+    split2(v[2 * j], v[2 * j + 1], a, b);
+    h[j] = a;
+    l[j] = b;
   }
+  hi = __builtin_bit_cast(half8, h);
+  lo = __builtin_bit_cast(half8, l);
 }
 
 // Store 8 consecutive columns [k, k+8) of one hl32 row.

@@ -75,6 +75,9 @@ __device__ inline unsigned queue_take(unsigned* queue) {
   return __hip_atomic_fetch_add(queue + (blockIdx.x & 7) + zero, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ inline int queue_resolve(unsigned* queue, unsigned ticket, int id_lo, int id_hi) {
+  // the first USE of the ticket stays here: without this hipcc hoists the id arithmetic up to the atomic (same branch
+  // of thread 0) and waits for the round trip on the spot
+  asm volatile("" : "+v"(ticket) :: "memory");
   const int x = blockIdx.x & 7;
   long long cand = (long long)id_lo + 8ll * ticket + x;
   int got = cand < id_hi ? (int)cand : -1;

@@ -21,10 +21,23 @@
 // A(t+1), B(t+1) has landed; nobody reads B(t) any more and A(t) went to registers a stage ago
 //   -> A(t+2) goes into A(t)'s slot (one stage of cover), B(t+3) into B(t)'s slot (two stages).
 // Tiles: persistent workgroups pull them from gemm_hl2.h's per-XCD-slot queues (dynamic), or one workgroup per tile.
+// Between two tiles of a persistent workgroup (stamps: scratch/wait_timing_g7.py, profiles/r05_allpairs_g7_timing.txt):
+//   * the ticket of the next tile is pulled three stages before the k loop ends and resolved right after it, so ONE
+//     barrier (the one that retires the ring) also hands over the tile id;
+//   * a tile whose eight 64 x 96 blocks all reduce from registers (inside the problem, off the diagonal: 98 % of them at
+//     N = 83) gets its squared norms by DMA into a small LDS buffer together with its first stage, so its epilogue issues no
+//     global load - and the first stages of the NEXT tile are issued before that epilogue starts: the 5 us cold start of a
+//     tile's operand stream runs under the reductions of the tile before it.
 //
 // Arithmetic: per output element the same chain as gemm_hl2.h's FLUSH kernel - stages in k order, passes hi*lo, lo*hi,
 // hi*hi, the MFMA accumulator added into the second one every 16 stages - so the two kernels agree to the bit
-// (tests/test_gemm_generations_gpu.py, scratch/ab_pairmin.py).
+// (tests/test_gemm_generations_gpu.py::test_all_pairs_tiles_agree_bitwise, scratch/ab_pairmin.py).
+//
+// Measured (MI355X, N = 83, same box, interleaved; profiles/r05_allpairs_256x192_ab.txt): -3.6 ... -4.5 % against the
+// 256x128 kernel; fabric traffic 88.6 -> 67.3 GB per launch, MFMA-pipe occupancy 73.5 -> 76.5 % at the SAME 1.63 GHz (the
+// package stays at its power cap: the joules the operand stream no longer takes go into more MFMAs per second, not into
+// clock).  Not kept (scratch/exp_g7_stagger_and_knobs.patch): a half-stage stagger of waves 4-7 (+10 ... +18 %), DMA issue
+// from all eight waves (+8 %), priority variants (0 ... +1 %).
 #pragma once
 #include "gemm_hl2.h"
 
@@ -41,7 +54,10 @@ constexpr int NTN = 6;                                   // 16-column MFMA tiles
 constexpr int A_HALF = BM * 128, B_HALF = BN * 128;      // 32 KB, 24 KB per stage
 constexpr int A_SLOTS = 2, B_SLOTS = 3;
 constexpr int LDS_BYTES = A_SLOTS * A_HALF + B_SLOTS * B_HALF;   // 136 KB
-constexpr int LDS_EXTRA = 16;                            // the next tile id of a dynamic walk
+// behind the ring: two buffers for the squared norms of a tile's 256 rows + 192 columns (the epilogue of a tile whose
+// blocks all reduce from registers reads them from LDS; they arrive with the tile's first stage), then the next tile id
+constexpr int NORM_BYTES = 2048, LDS_NORMS = 2 * NORM_BYTES;
+constexpr int LDS_EXTRA = LDS_NORMS + 16;
 constexpr int FLUSH_STAGES = gemm::FLUSH_STAGES;
 
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE7=1 no DMA in the k loop, 2 no fragment reads in the
@@ -50,31 +66,48 @@ constexpr int FLUSH_STAGES = gemm::FLUSH_STAGES;
 #define AC_ABLATE7 0
 #endif
 
+// -DAC_G7_TIMING (diagnostic builds; read back with ac_debug_wait_times7, alpha.hip): waves 0 and 4 of every persistent
+// workgroup add up the shader-clock cycles they spend in the prologue of a tile, in its k loop, inside that at X waiting
+// for their own DMA (vmcnt) and then for the other waves (lgkmcnt + barrier), and in the epilogue up to the next tile id.
+#ifdef AC_G7_TIMING
+static __device__ unsigned long long ac_wait_times7[1024 * 2 * 8];
+#define G7_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
+#define G7_TACC(v) v += __builtin_readcyclecounter() - t0_
+#else
+#define G7_T0()
+#define G7_TACC(v)
+#endif
+
 // ---- upper triangle of a symmetric problem on 256-row x 192-column tiles.  Tile (p, c) holds rows [256 p, +256) and
 // columns [192 c, +192); it contains an element with column >= row iff c >= c0(p) = floor(4 p / 3).
 __host__ __device__ inline int tri_c0(int p) { return (4 * p) / 3; }
-// tiles in the tile rows above p: p Tn - sum_{i < p} floor(4 i / 3); with p = 3 a + b the sum is 6 a^2 - 3 a + 4 a b + [b == 2]
-__host__ __device__ inline long long tri_rows_before(int p, int Tn) {
-  const long long a = p / 3, b = p % 3;
-  return (long long)p * Tn - (6 * a * a - 3 * a + 4 * a * b + (b == 2 ? 1 : 0));
+// tiles in the tile rows above p: p Tn - sum_{i < p} floor(4 i / 3); with p = 3 a + b the sum is 6 a^2 - 3 a + 4 a b + [b == 2].
+// 32-bit: the launcher refuses problems with Tm * Tn >= 2^31.
+__host__ __device__ inline int tri_rows_before(int p, int Tn) {
+  const int a = p / 3, b = p - 3 * a;
+  return p * Tn - (6 * a * a - 3 * a + 4 * a * b + (b == 2 ? 1 : 0));
 }
 // Linear order made for the L2, as gemm_hl2.h's: groups of G tile rows; inside a group the ACTUAL column runs slowest
 // and the row fastest, so that a contiguous run of the order (what one XCD works on at a time) covers G row panels and
-// the few column panels they share.
+// the few column panels they share.  (This runs once per tile on the scalar unit, between two tiles of a persistent
+// workgroup, with the MFMA pipe idle: kept short - 32-bit, one square root, no division but by constants.)
 __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn) {
-  // row p with F(p) <= lin < F(p + 1), F(p) ~ p Tn - (2/3) p^2
-  const double t = (double)Tn;
-  int p = (int)(0.75 * (t - sqrt(fmax(t * t - (8.0 / 3.0) * (double)lin, 0.0))));
+  // row p with F(p) <= lin < F(p + 1): F(p) = p (Tn + 1) - (2/3) p^2 - {0, 1/3, 1/3}[p % 3], so the root of the
+  // quadratic is within a row of the answer (single precision is enough: the loops below settle the last step)
+  int tn1 = Tn + 1;
+  asm volatile("" : "+s"(tn1));                         // (rebuilt per tile: hoisted out of the tile loop it is spilled)
+  const float t = (float)tn1;
+  int p = (int)(0.75f * (t - sqrtf(fmaxf(t * t - (8.0f / 3.0f) * (float)lin, 0.0f))));
   p = max(0, min(p, Tm - 1));
   while (p > 0 && tri_rows_before(p, Tn) > lin) --p;
   while (p + 1 < Tm && tri_rows_before(p + 1, Tn) <= lin) ++p;
-  const int p0 = (p / G) * G, gsz = min(G, Tm - p0);
-  int w = lin - (int)tri_rows_before(p0, Tn);           // index inside the group
+  const int p0 = p - p % G, gsz = min(G, Tm - p0);
+  int w = lin - tri_rows_before(p0, Tn);                // index inside the group
   int c = tri_c0(p0);
   const int c_full = tri_c0(p0 + gsz - 1);              // from this column on every row of the group is valid
   int r = 0;
   for (;;) {                                            // ragged head: at most 4 (G - 1) / 3 + 1 columns
-    if (c >= c_full) { c = c_full + w / gsz; r = w % gsz; break; }
+    if (c >= c_full) { const int q = w / gsz; c = c_full + q; r = w - q * gsz; break; }
     const int v = min(gsz, (3 * c + 2) / 4 - p0 + 1);   // rows p0 .. with c0(row) <= c
     if (w < v) { r = w; break; }
     w -= v;
@@ -84,11 +117,11 @@ __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn
   tn = c;
 }
 
+// `total`: the launch's tile count (the launcher passes it: tri_rows_before(Tm, Tn) for a symmetric problem)
 template <class Epi>
-__device__ inline void tile_of(int id, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
+__device__ inline void tile_of(int id, int total, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {
-      const long long total = tri_rows_before(tiles_m, tiles_n);
       tri_tile(gemm2::xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m, tm, tn);
       return;
     }
@@ -99,12 +132,13 @@ __device__ inline void tile_of(int id, int tiles_m, int tiles_n, int group_m, co
 template <class Epi>
 __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
-                                                     int id_lo, int id_hi, Epi epi, unsigned* queue) {
+                                                     int id_lo, int id_hi, int total, Epi epi, unsigned* queue) {
+  static_assert(LDS_BYTES + LDS_EXTRA <= 160 * 1024, "LDS");
   static_assert(!gemm::HasSwap<Epi>::value && EpiTraits<Epi>::kSymmetric, "gemm_hl7 serves the pair-min epilogue");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const Aring = smem;
   uint8_t* const Bring = smem + A_SLOTS * A_HALF;
-  int* const lds_next = reinterpret_cast<int*>(smem + LDS_BYTES);
+  int* const lds_next = reinterpret_cast<int*>(smem + LDS_BYTES + LDS_NORMS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -117,24 +151,25 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   // Registers are what this kernel is short of (240 of 256 hold accumulators and fragments), so the per-lane DMA state
   // is the lane number alone: row and chunk are rebuilt at every burst, and the lane number is redefined by an empty
   // asm there - hipcc would otherwise hoist the 14 row offsets of a stage out of the k loop (28 registers, spilled).
-  const bool loader = wave < 4;
+  constexpr int LW = 4;                          // DMA-issuing waves (all eight: +7 %, round-5 A/B)
+  const bool loader = wave < LW;
   if (loader) __builtin_amdgcn_s_setprio(2);
   const unsigned ld32 = (unsigned)K * 4u;
   int m0 = 0, n0 = 0;
   auto dma = [&](const uint8_t* src, int first, int last, int t, uint8_t* dst, int pieces) {
     int l = lane;
     asm volatile("" : "+v"(l));
-    const int r = (wave & 3) * 8 + (l >> 3);
+    const int r = (wave & (LW - 1)) * 8 + (l >> 3);
     const uint8_t* base = src + (size_t)t * 128 + (unsigned)((l & 7) ^ ((r >> 1) & 7)) * 16u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j >= pieces) break;
-      const unsigned row = (unsigned)min(first + r + 32 * j, last);
-      __builtin_amdgcn_global_load_lds((gptr_t)(base + (uint64_t)row * ld32), (lptr_t)(dst + (j * 4 + (wave & 3)) * 1024), 16, 0, 0);
+      const unsigned row = (unsigned)min(first + r + 8 * LW * j, last);
+      __builtin_amdgcn_global_load_lds((gptr_t)(base + (uint64_t)row * ld32), (lptr_t)(dst + (j * LW + (wave & (LW - 1))) * 1024), 16, 0, 0);
     }
   };
-  auto dmaA = [&](int t, int slot) { if (loader) dma(A, m0, M - 1, t, Aring + slot * A_HALF, BM / 32); };
-  auto dmaB = [&](int t, int slot) { if (loader) dma(B, n0, N - 1, t, Bring + slot * B_HALF, BN / 32); };
+  auto dmaA = [&](int t, int slot) { if (loader) dma(A, m0, M - 1, t, Aring + slot * A_HALF, BM / (8 * LW)); };
+  auto dmaB = [&](int t, int slot) { if (loader) dma(B, n0, N - 1, t, Bring + slot * B_HALF, BN / (8 * LW)); };
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
 
   // fragment offsets: 16-row tile t of this wave's rows / columns is base + t * 2048 bytes (the XOR swizzle term
@@ -165,10 +200,45 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     if (id >= id_hi) return;
   }
 
+#ifdef AC_G7_TIMING
+  unsigned long long tt_pro = 0, tt_loop = 0, tt_vm = 0, tt_bar = 0, tt_epi = 0, tt_tiles = 0, tt_e1 = 0, tt_e2 = 0;
+  const unsigned long long tt_start = __builtin_readcyclecounter();
+#endif
+  // The first stages of a tile - A(0) B(0) A(1) B(1) B(2), in that order - are issued BEFORE the epilogue of the tile in
+  // front of it whenever that epilogue works from registers alone (a "fast" tile: every 64 x 96 block inside the problem
+  // and off the diagonal), so the cold start of a tile's operand stream (5 us) runs under the previous tile's reductions.
+  // A fast tile's squared norms travel the same way, FIRST in the queue (waves 0 and 1, one DMA instruction each: 256
+  // row norms, 192 column norms) into one of two small LDS buffers: its epilogue then issues no global load at all - a
+  // wave's memory operations retire in order, so norm loads issued behind the next tile's 34 transfers would return
+  // microseconds late, and issued in front of them they cost 22 registers this kernel does not have.
+  bool fast_next = false;      // the tile whose prologue was issued last is fast (its norms are in LDS buffer norm_par)
+  int norm_par = 1;
+  auto issue_prologue = [&]() {
+    fast_next = epi.tile_is_fast(m0, n0, BM, BN, NTN * 16);
+    norm_par ^= 1;
+    if (fast_next && wave < 2) {
+      const float* src = wave == 0 ? epi.key_sq + m0 : epi.qry_sq + n0;
+      const int l4 = wave == 0 || lane < BN / 4 ? lane * 4 : 0;           // column norms: 48 lanes carry data
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + l4), (lptr_t)(smem + LDS_BYTES + norm_par * NORM_BYTES + wave * 1024), 16, 0, 0);
+    }
+    dmaA(0, 0);
+    dmaB(0, 0);
+    if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
+    if (nk > 2) dmaB(2, 2);
+  };
+  tile_of(id, total, tiles_m, tiles_n, group_m, epi, tm, tn);            // block-uniform
+  m0 = tm * BM;
+  n0 = tn * BN;
+  issue_prologue();
+  bool counted = true;
+  int n_behind = 0;
   for (;;) {
-    tile_of(id, tiles_m, tiles_n, group_m, epi, tm, tn);          // block-uniform
-    m0 = tm * BM;
-    n0 = tn * BN;
+#ifdef AC_G7_TIMING
+    const unsigned long long tt_a = __builtin_readcyclecounter();
+#endif
+    const int m0c = m0, n0c = n0;                                 // this tile (m0, n0 move on to the next one early)
+    const bool fast_cur = fast_next;                              // ... is fast, its norms are in LDS buffer norm_cur
+    const int norm_cur = norm_par;
     f32x4 acc[4][NTN], tot[4][NTN];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -177,25 +247,37 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[mi][ni][i] = 0.f; tot[mi][ni][i] = 0.f; }
 
-    // prologue: A(0) B(0) A(1) B(1) B(2) in that order; the first two must have landed
-    dmaA(0, 0);
-    dmaB(0, 0);
-    if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
-    if (nk > 2) dmaB(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / 32 + 2 * (BN / 32)) : "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / 32 + BN / 32) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the first two of the five prologue transfers must have landed (only waves that issued any wait).  Behind them
+    // in the wave's queue: the other three and - early prologue - the epilogue's atomicMins, which take microseconds
+    // to retire under load and need not be waited for.
+    if (loader) {
+      constexpr int REST = BM / (8 * LW) + 2 * (BN / (8 * LW));      // A(1) B(1) B(2)
+      if (nk <= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST) : "memory");
+      else switch (n_behind) {
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 2) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 3) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 4) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 5) : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 6) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+    }
     barrier();
     half8 ah[4], al[4], bh, bl;
 #pragma unroll
     for (int t = 0; t < 4; ++t) frag(0, a_hi, t, ah[t], al[t]);
     frag(B0, b_hi, 0, bh, bl);
+#ifdef AC_G7_TIMING
+    const unsigned long long tt_b = __builtin_readcyclecounter();
+    tt_pro += tt_b - tt_a;
+#endif
 
-    int sb = 0;                                    // B slot of the current stage (kt % 3)
+    int sb = 0;                                    // B slot of the current stage (kt % B_SLOTS)
     auto stage = [&](int kt, auto steady) {
       constexpr bool STEADY = decltype(steady)::value;   // branch-free body while three more stages follow
       const bool more1 = STEADY || kt + 1 < nk, more2 = STEADY || kt + 2 < nk, more3 = STEADY || kt + 3 < nk;
-      const int sb1 = sb == 2 ? 0 : sb + 1;        // (kt + 1) % 3
+      const int sb1 = sb == B_SLOTS - 1 ? 0 : sb + 1;    // (kt + 1) % B_SLOTS
       const int Bs = B0 + sb * B_HALF, Bn = B0 + sb1 * B_HALF, An = ((kt + 1) & 1) * A_HALF;
       // One column step = three passes over the four row tiles (per element the passes stay in the order hi*lo, lo*hi,
       // hi*hi).  The lo half of the B fragment is dead after the first pass: the next step's fragment is read right
@@ -207,15 +289,19 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
         const bool last = ni == NTN - 1;
         if (!(AC_ABLATE7 & 4)) {
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+          for (int mi = 0; mi < 4; ++mi)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (last && more1) {
           // own share of A(kt+1), B(kt+1) landed: B(kt+2) (6 instructions, the youngest) may still fly
-          if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BN / 32) : "memory");
+          G7_T0();
+          if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BN / (8 * LW)) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          G7_TACC(tt_vm);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           barrier();                               // X(kt)
+          G7_TACC(tt_bar);
         }
         half8 nh = bh;
         if (AC_ABLATE7 & 2) {
@@ -255,29 +341,71 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       }
       sb = sb1;
     };
+    // k loop.  Dynamic walk: thread 0 pulls the next tile's ticket three stages before the end and turns it into a
+    // tile id after the last stage, so the round trip of the atomic hides under MFMA work and the id is in LDS when the
+    // post-loop barrier opens - one barrier hands over the tile.
     int kt = 0;
     for (; kt + 3 < nk; ++kt) stage(kt, std::true_type{});
+    unsigned ticket = 0;
+    if (queue && tid == 0) ticket = take();
     for (; kt < nk; ++kt) stage(kt, std::false_type{});
+    // EVERY lane consumes the ticket register here: hipcc's wait-count pass merges paths, and with the atomic and its
+    // use in two separate `tid == 0` branches it would otherwise believe the register still pending all round the
+    // tile loop and put an s_waitcnt vmcnt(0) in front of every reuse of that register - between the DMA bursts of the
+    // early prologue, for one.
+    asm volatile("" : "+v"(ticket));
+    if (queue && tid == 0) resolve(ticket);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();                                     // ring reads done: an epilogue / the next prologue may reuse LDS
+#ifdef AC_G7_TIMING
+    const unsigned long long tt_c = __builtin_readcyclecounter();
+    tt_loop += tt_c - tt_b;
+    ++tt_tiles;
+#endif
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NTN; ++ni)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[mi][ni][i] += tot[mi][ni][i];
-
-    unsigned ticket = 0;
-    if (queue && tid == 0) ticket = take();        // in flight beside the epilogue's own loads; resolved after it
-
+    const int m_wave = m0c + wm * 64, n_wave = n0c + wn * (NTN * 16);
+    int next = -1;
+    bool early = false;
+    if (queue) {
+      next = __builtin_amdgcn_readfirstlane(*lds_next);        // block-uniform: the tile arithmetic stays scalar
+      if (next >= 0) {
+        tile_of(next, total, tiles_m, tiles_n, group_m, epi, tm, tn);
+        m0 = tm * BM;
+        n0 = tn * BN;
+        early = fast_cur;                                      // no wave of this tile touches the ring any more
+        if (early) issue_prologue();
+      }
+    }
+#ifdef AC_G7_TIMING
+    const unsigned long long tt_d = __builtin_readcyclecounter();
+    tt_e1 += tt_d - tt_c;
+#endif
+#ifdef AC_G7_TIMING
+    const unsigned long long tt_e = __builtin_readcyclecounter();
+    tt_e2 += tt_e - tt_d;
+#endif
     // ---- epilogue: the wave's 64 x 96 block at rows m_wave, columns n_wave
-    const int m_wave = m0 + wm * 64, n_wave = n0 + wn * (NTN * 16);
     const bool sym = epi.symmetric;
+    int n_atomics = 0;
     // symmetric problem: only elements with row <= column are used, each reduced in both directions (gemm_hl2.h).
     // A block wholly above the diagonal and inside the problem: both reductions from registers (epi.fast_wide);
     // otherwise the general code on a 64 x 64 and a 64 x 32 piece, per-element diagonal mask where a piece crosses it.
     const bool below = sym && m_wave > n_wave + (NTN * 16 - 1);
-    if (!below) {
+    if (fast_cur) {
+      const float* nb = reinterpret_cast<const float*>(smem + LDS_BYTES + norm_cur * NORM_BYTES);
+      f32x4 ks[4];
+      float qs[NTN];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(nb + wm * 64 + 16 * mi + 4 * (lane >> 4));
+#pragma unroll
+      for (int ni = 0; ni < NTN; ++ni) qs[ni] = nb[256 + wn * (NTN * 16) + 16 * ni + (lane & 15)];
+      n_atomics = epi.template fast_reduce<NTN>(acc, ks, qs, m_wave, n_wave, lane, sym || epi.two_way);
+    } else if (!below) {
       const bool both = sym || epi.two_way;
       const bool clear = !sym || m_wave + 63 <= n_wave;
       if (!(clear && epi.template fast_wide<NTN>(acc, m_wave, n_wave, lane, both))) {
@@ -300,14 +428,23 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       }
     }
 
-    if (!queue) break;
-    if (tid == 0) resolve(ticket);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // thread 0's block id is in LDS; everyone is out of the ring
-    barrier();
-    id = *lds_next;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    barrier();                                     // ... and has read the id before the next pull overwrites it
-    if (id < 0) break;
+#ifdef AC_G7_TIMING
+    tt_epi += __builtin_readcyclecounter() - tt_c;
+    if (next < 0 && (tid == 0 || tid == 256) && blockIdx.x < 1024) {
+      unsigned long long* o = ac_wait_times7 + (blockIdx.x * 2 + (tid >> 8)) * 8;
+      o[0] = tt_tiles; o[1] = tt_pro; o[2] = tt_loop; o[3] = tt_vm; o[4] = tt_bar - tt_vm; o[5] = tt_epi;
+      o[6] = __builtin_readcyclecounter() - tt_start; o[7] = nk | (tt_e1 / (tt_tiles ? tt_tiles : 1)) << 16 | (tt_e2 / (tt_tiles ? tt_tiles : 1)) << 40;
+    }
+#endif
+    if (next < 0) break;                           // every queue is exhausted (or: one workgroup per tile)
+    if (!early) {                                  // the general epilogue used the ring as scratch: everyone is out of it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      barrier();
+      issue_prologue();
+    }
+    counted = !early;
+    n_behind = n_atomics;                          // early: that many atomicMins were issued behind the DMA
+    id = next;
   }
 }
 
@@ -321,11 +458,11 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   if (group_m < 1) return ac_fail(AC_EINVAL, "gemm_hl7: group_m=%d must be positive", group_m);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   long long total = (long long)tiles_m * tiles_n;
+  if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl7: grid too large");
   if (epi.symmetric) {
     if (M != N) return ac_fail(AC_EINVAL, "gemm_hl7: symmetric epilogue needs M == N");
     total = tri_rows_before(tiles_m, tiles_n);
   }
-  if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl7: grid too large");
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
   if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi>), LDS_BYTES + LDS_EXTRA, &attr_done)) return rc;
   const long long lo = (total * part / nparts) & ~7LL;
@@ -340,7 +477,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   }
   hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
-                     group_m, (int)lo, (int)hi, epi, queue);
+                     group_m, (int)lo, (int)hi, (int)total, epi, queue);
   return ac_check_launch("gemm_hl7");
 }
 

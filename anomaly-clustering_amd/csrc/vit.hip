@@ -660,13 +660,21 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     }
     float psum = 0.f;
     half8 ph[2], pl[2];
+    {
+      u32x4 phw[2], plw[2];                // the hi / lo split of P two scores at a time (common.h split2: 1.5 VALU per score)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float p = __builtin_amdgcn_exp2f(fmaf(s_acc[i], c_log2, -m_new));
-      psum += p;
-      _Float16 hi = (_Float16)p;
-      ph[i >> 3][i & 7] = hi;
-      pl[i >> 3][i & 7] = (_Float16)(p - (float)hi);
+      for (int i = 0; i < 16; i += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s_acc[i], c_log2, -m_new));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s_acc[i + 1], c_log2, -m_new));
+        psum += p0;
+        psum += p1;
+        uint32_t a, b;
+        split2(p0, p1, a, b);
+        phw[i >> 3][(i & 7) >> 1] = a;
+        plw[i >> 3][(i & 7) >> 1] = b;
+      }
+      ph[0] = __builtin_bit_cast(half8, phw[0]); ph[1] = __builtin_bit_cast(half8, phw[1]);
+      pl[0] = __builtin_bit_cast(half8, plw[0]); pl[1] = __builtin_bit_cast(half8, plw[1]);
     }
     l_run += psum;
     // O^T += V^T P^T ; A fragment element j <-> key 16s + 8h + j (the transposed reads were issued above)

@@ -31,6 +31,8 @@ class BlockWeights(_c.Structure):
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
+ABI_VERSION = 500      # include/ac_hip.h AC_ABI_VERSION
+
 # name -> (restype, argtypes): every symbol include/ac_hip.h declares
 SIGNATURES = {
     "ac_version": (_i, []),
@@ -68,7 +70,8 @@ SIGNATURES = {
     "ac_gather_rows": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "ac_nn_scatter_exhaustive": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "ac_nn_finalize": (_i, [_vp, _i64, _vp, _vp]),
-    "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp, _vp]),
+    "ac_alpha_softmax": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp]),
+    "ac_alpha_softmax_f32": (_i, [_vp, _i64, _i, _d, _d, _vp, _vp, _vp]),
     "ac_weighted_avg": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "ac_pdist": (_i, [_vp, _i64, _i, _vp, _vp]),
     "ac_ward_workspace_bytes": (_sz, [_i64]),
@@ -94,6 +97,9 @@ def lib():
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(handle, name)       # AttributeError if the ABI is incomplete
                     fn.restype, fn.argtypes = res, args
+                if handle.ac_version() != ABI_VERSION:
+                    raise RuntimeError("%s has ABI revision %d, this binding is written for %d (include/ac_hip.h "
+                                       "AC_ABI_VERSION): rebuild the library" % (LIB_PATH, handle.ac_version(), ABI_VERSION))
                 _lib = handle
     return _lib
 
@@ -704,7 +710,7 @@ def alpha_softmax(w, tau, k=1.0, want_f32=False):
     a = torch.empty((N, P), dtype=torch.float64, device=w.device)
     a32 = torch.empty((N, P), dtype=torch.float32, device=w.device) if want_f32 else None
     if N:
-        _check(lib().ac_alpha_softmax(p, N, P, float(tau), float(k), a.data_ptr(), a32.data_ptr() if want_f32 else None, _stream()))
+        _check(lib().ac_alpha_softmax_f32(p, N, P, float(tau), float(k), a.data_ptr(), a32.data_ptr() if want_f32 else None, _stream()))
     return (a, a32) if want_f32 else a
 
 

@@ -790,6 +790,12 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
     return ops.pair_finalize(acc, P, MIN, m, None)
 
 
+def _flag_device(ops, images):
+    """Where a one-word flag of a collective lives: the seam's device (gloo stand-ins without a core: the images')."""
+    core = getattr(ops, "core", None)
+    return core.device if core is not None else images.device
+
+
 def _zinfo(ops, Z):
     """(images, patches per image, device) of a rank's embeddings: Z fp32 [n, P, D], or the Taps a lean run keeps instead."""
     if isinstance(Z, Taps):
@@ -1037,13 +1043,13 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
     if Z_locs is not None and (len(Z_locs) != ncat or any(z is None for z in Z_locs)):
         raise ValueError("Z_locs must hold the embeddings of every category")
 
-    def one(c):
+    def one(c, rot=0):
         it = items[c]
         return run_category(ops, it["images"], supervised, tau=tau, k=k, train_images=it.get("train_images"),
                             Z_loc=Z_locs[c] if Z_locs is not None else None,
                             train_ratio=train_ratio, group=group, bank_seed=bank_seed, want_pdist=want_pdist,
                             want_host=want_host, timings=timings, budget=budget, remote_bytes=remote_bytes, prune=prune,
-                            solo=solo)
+                            solo=solo, rot=rot)
 
     if schedule == "sequential":
         return [one(c) for c in range(ncat)]
@@ -1067,6 +1073,21 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
                 for c in range(ncat)]
     outs = [None] * ncat
     for grp in _groups(per_rank, group_images):
+        # A group that must run LEAN (taps instead of Z: the rank's Z + packed copy of the group would not fit, or the
+        # caller hands back the Taps an earlier lean run returned as out["Z_loc"]) goes category by category through
+        # run_category, which has the lean path; the one-job order below holds full Z.  Every rank must take the same
+        # branch (the two orders post different collectives), so the ranks agree on the flag first.  (Round-4 advice: the
+        # one-job path used to read Z_locs[c].shape of a Taps object and to embed large groups with full Z.)
+        lean_grp = Z_locs is not None and any(isinstance(Z_locs[c], Taps) for c in grp)
+        lean_grp = lean_grp or bool(getattr(ops, "wants_lean", lambda _n: False)(sum(per_rank[c] for c in grp)))
+        if world > 1:
+            flag = torch.tensor([int(lean_grp)], dtype=torch.int32, device=_flag_device(ops, items[grp[0]]["images"]))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            lean_grp = bool(int(flag.item()))
+        if lean_grp:
+            for c in grp:
+                outs[c] = one(c, rots[c])
+            continue
         # ---- 1. one stream of ViT batches for the group
         t0 = time.perf_counter()
         sets = []
@@ -1074,9 +1095,9 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
             sets = [items[c]["images"][all_bounds[c][vr[c]][0]: all_bounds[c][vr[c]][1]] for c in grp]
         else:
             for c in grp:
-                if Z_locs[c].shape[0] != all_bounds[c][vr[c]][1] - all_bounds[c][vr[c]][0]:
+                if _zinfo(ops, Z_locs[c])[0] != all_bounds[c][vr[c]][1] - all_bounds[c][vr[c]][0]:
                     raise ValueError("Z_locs[%d] holds %d images, this rank's shard has %d"
-                                     % (c, Z_locs[c].shape[0], all_bounds[c][vr[c]][1] - all_bounds[c][vr[c]][0]))
+                                     % (c, _zinfo(ops, Z_locs[c])[0], all_bounds[c][vr[c]][1] - all_bounds[c][vr[c]][0]))
         ntest = len(sets)
         if supervised == "supervised":
             for c in grp:

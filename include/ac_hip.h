@@ -47,6 +47,10 @@ extern "C" {
 #define AC_EWORKSPACE 2 /* workspace too small */
 #define AC_ELAUNCH 3    /* HIP reported a launch error */
 
+/* ABI revision: changes whenever an entry point changes meaning or a new one is added; a binding checks it at load
+ * time (models/acnative does: a stale library under a newer binding - or the reverse - fails there, not in a kernel).
+ * 500 = round 5: ac_alpha_softmax is the 7-argument form again, the fp32 copy moved to ac_alpha_softmax_f32. */
+#define AC_ABI_VERSION 500
 int ac_version(void);
 const char* ac_last_error(void);
 
@@ -270,9 +274,14 @@ int ac_nn_finalize(const double* best_d2, int64_t n, float* w, void* stream);
 /* The softmax half of Matrix_Alpha_* (utils.py:246-254 / 266-274), float64:
  *   tau == 0 (what math.isclose(tau, 0) accepts): alpha = [w == max w] / #ties;
  *   else alpha = k*exp(w/tau) / sum, computed max-shifted (same value, no overflow).
- * w fp32 [N, P] -> alpha fp64 [N, P]; alpha_f32 (optional, may be NULL): fp32 [N, P], the same values rounded once -
- * what examples/main.py:294 obtains with `matrix_alpha.float()` before the bmm. */
-int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, float* alpha_f32, void* stream);
+ * w fp32 [N, P] -> alpha fp64 [N, P].
+ * ac_alpha_softmax_f32 also writes alpha_f32 (fp32 [N, P], may be NULL): the same values rounded once - what
+ * examples/main.py:294 obtains with `matrix_alpha.float()` before the bmm.  (Round 4 had inserted that argument into
+ * ac_alpha_softmax itself; a caller built against the 7-argument form would then have passed its stream as a pointer
+ * to write through.  The old symbol keeps the old signature; new functionality gets a new name.) */
+int ac_alpha_softmax(const float* w, int64_t N, int P, double tau, double k, double* alpha, void* stream);
+int ac_alpha_softmax_f32(const float* w, int64_t N, int P, double tau, double k, double* alpha, float* alpha_f32,
+                         void* stream);
 
 /* examples/main.py:294-296: X[i] = alpha[i] (fp32 [P]) . Z[i] (fp32 [P, D]) -> fp32 [N, D]. */
 int ac_weighted_avg(const float* alpha, const float* Z, int64_t N, int P, int D, float* X, void* stream);

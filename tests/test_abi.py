@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), "libac_hip.so does not export %s" % name
     assert sorted(acnative.SIGNATURES) == names, "binding table and header disagree"
-    assert lib.ac_version() >= 100
+    assert lib.ac_version() == acnative.ABI_VERSION == 500      # include/ac_hip.h AC_ABI_VERSION
 
 
 def test_header_cites_reference_for_every_compute_entry_point():
@@ -45,7 +45,8 @@ def test_argument_validation_without_gpu():
     rc = lib.ac_pair_min_dist(ctypes.c_void_p(16), 2, ctypes.c_void_p(16), 2, 8, 64, 0, 0, ctypes.c_void_p(16),
                               ctypes.c_void_p(16), 16, None)
     assert rc == 2 and b"workspace" in lib.ac_last_error()
-    assert lib.ac_alpha_softmax(ctypes.c_void_p(16), 2, 8, -1.0, 1.0, ctypes.c_void_p(16), None, None) == 1
+    assert lib.ac_alpha_softmax(ctypes.c_void_p(16), 2, 8, -1.0, 1.0, ctypes.c_void_p(16), None) == 1
+    assert lib.ac_alpha_softmax_f32(ctypes.c_void_p(16), 2, 8, -1.0, 1.0, ctypes.c_void_p(16), None, None) == 1
     assert lib.ac_pair_min_dist_workspace_bytes(167, 167, 784, 4096) > 2 * 167 * 784 * 4096 * 4 // 2
     assert lib.ac_vit_workspace_bytes(32, 785, 768, 3072, 12, 192) > 32 * 785 * 3072 * 4
 

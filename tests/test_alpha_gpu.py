@@ -40,6 +40,32 @@ def _truth_w(Zq, Zk, reduce, self_offset=0):
     return out
 
 
+def test_hl32_split_is_the_two_fp16_roundings_bit_for_bit(dev):
+    """hl32 = (hi, lo) with hi = fp16(x), lo = fp16(x - hi).  The device forms lo with
+    v_fma_mix{lo,hi}_f16 (common.h split2: hi * (-1) + x in fp32, one rounding to fp16); x - float(hi) is exact in fp32, so the
+    planes must equal the two plain roundings BIT FOR BIT - on ordinary values, on the fp16 boundaries (subnormal lo halves,
+    the largest finite hi, values that round to inf) and on inf / nan."""
+    import acnative
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((64, 256), generator=g)
+    x[1] *= 1e-3
+    x[2] *= 1e3
+    x[3] *= 6e-5                     # fp16 subnormal hi halves
+    x[4] *= 1e-7                     # lo halves (and hi halves) far below the smallest fp16 subnormal
+    x[5] = torch.linspace(65400.0, 65540.0, 256)      # across the largest finite fp16 (65504) and the rounding boundary 65520
+    x[6, :8] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 65504.0, 65519.996, 2.0 ** -24])
+    x[7] = torch.arange(256, dtype=torch.float32) * 2.0 ** -14 + 1.0     # ties of the hi rounding (round to nearest even)
+    hl = acnative.pack_hl32(x.to(dev)).cpu().reshape(64, 256 // 32, 2, 32, 2)         # [row][group][plane][k][byte]
+    got_hi = hl[:, :, 0].reshape(64, 256, 2).contiguous().view(torch.float16).reshape(64, 256)
+    got_lo = hl[:, :, 1].reshape(64, 256, 2).contiguous().view(torch.float16).reshape(64, 256)
+    hi = x.to(torch.float16)
+    lo = (x - hi.to(torch.float32)).to(torch.float16)
+    for got, ref, name in ((got_hi, hi, "hi"), (got_lo, lo, "lo")):
+        nan = torch.isnan(ref)
+        assert torch.equal(torch.isnan(got), nan), name
+        assert torch.equal(got.view(torch.int16)[~nan], ref.view(torch.int16)[~nan]), name
+
+
 def test_small_all_taus_against_reference_golden(golden, dev):
     import acnative
     g = golden("alpha_small.npz")

@@ -58,7 +58,8 @@ def _check_all15(d, mode):
     assert 0 < roof["frac"] < (2 / 3 if mode == "unsupervised" else 1.0)
     # the committed PMC summary of THIS workload (profiles/r03_config*_pmc.json) supplies the HBM-side bytes
     assert roof["traffic"] is not None and roof["traffic"] > 0 and roof["traffic_source"].startswith("profiles/")
-    assert set(d["stage_ms"]) >= {"embed", "pair_min_dist", "pdist"} and d["h2d_inclusive"]["value"] > 0
+    assert set(d["stage_ms"]) >= {"embed", "pair_min_dist", "pdist"} and d["images_resident"]["value"] > 0
+    assert "pinned host memory" in d["config"]["input"]       # `value` starts at the H2D copy
 
 
 @pytest.mark.parametrize("schedule", ["pipeline", "sequential", "per_gpu"])

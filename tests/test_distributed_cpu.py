@@ -408,7 +408,7 @@ class ToyTapsOps(ToyOps):
     pack_taps = taps_to_packed
 
     def weighted_avg_taps(self, alpha_f32, taps):
-        return self.weighted_avg(alpha_f32.reshape(taps.n, -1), self._z(taps))
+        return self.weighted_avg(alpha_f32.reshape(taps.n, self.P), self._z(taps))    # (n = 0: a rank without images)
 
 
 class ToyTapsPrunedOps(ToyTapsOps, ToyPrunedOps):
@@ -421,8 +421,16 @@ def _worker_taps(rank, world, init_file, out_dir, mode, many, kw):
     dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
     ops = ToyTapsPrunedOps(0, None) if mode == "supervised_pruned" else ToyTapsOps()
     m = "supervised" if mode.startswith("supervised") else mode
+    kw = dict(kw)
+    lean_rank, again = kw.pop("_lean_rank", None), kw.pop("_again_with_taps", False)
+    if lean_rank is not None:                      # ONE rank is short of memory: every rank must leave the one-job order
+        ops.wants_lean = lambda _n: rank == lean_rank
     if many:
         outs = run_categories(ops, _category_items(), m, tau=1.0, train_ratio=1.0, **kw)
+        if again:                                  # a second pass over the embeddings the lean first pass handed back (Taps)
+            from patchcore.pipeline import Taps
+            assert any(isinstance(o["Z_loc"], Taps) for o in outs) == (rank == lean_rank)   # only that rank dropped Z
+            outs = run_categories(ops, _category_items(), m, tau=1.0, train_ratio=1.0, Z_locs=[o["Z_loc"] for o in outs], **kw)
     else:
         images, train = _inputs()
         outs = [run_category(ops, images, m, tau=1.0, train_images=train, train_ratio=1.0, **kw)]
@@ -444,6 +452,8 @@ def _worker_taps(rank, world, init_file, out_dir, mode, many, kw):
     (3, "unsupervised", False, {"lean": True}),               # Z dropped: packed blocks and X rebuilt from the taps
     (2, "supervised", False, {"lean": True}),
     (2, "average", False, {"lean": True}),
+    (3, "unsupervised", True, {"_lean_rank": 1}),             # one-job order, one rank wants lean: all fall back together
+    (2, "supervised", True, {"_lean_rank": 0, "_again_with_taps": True}),   # ... and the Taps come back in as Z_locs
 ])
 def test_ring_of_taps_equals_ring_of_packed_shards(world, mode, many, kw):
     """Several ranks send the tapped feature maps round the ring (2.7x fewer bytes on the real shapes) and the receiver

@@ -54,6 +54,53 @@ def test_generations_agree_bitwise(dev):
         np.testing.assert_array_equal(auto[k], ref[k], err_msg="auto vs 256x128: %s" % k)
 
 
+def test_all_pairs_tiles_agree_bitwise(dev):
+    """Round 5: the all-pairs distance kernel runs on 256x192 tiles (csrc/gemm_hl7.h); ac_set_gemm_policy(256x128) pins the
+    round-4 kernel (csrc/gemm_hl2.h).  Per element both accumulate the same chain (k stages in order, passes hi*lo, lo*hi,
+    hi*hi, the MFMA accumulator flushed into the second one every 16 stages), every pair is formed with the lower row as
+    the A operand, and min is order-free - so every matrix of minima must be equal BIT FOR BIT, in every form of the launch:
+      * symmetric (triangle of tiles, persistent workgroups on the tile queues: 28 x 784 rows), whole and in 3 slices,
+      * symmetric on shapes whose blocks straddle the diagonal and the image boundaries in every way (P = 100, 67, 130; K
+        of 2, 3, 8 stages: below one flush interval, and past it with P = 784 / D = 640: 20 stages),
+      * two-way and one-way rectangles with ragged edges, one-image blocks included."""
+    import acnative
+    from _synth import clustered_embeddings
+
+    def both(fn):
+        try:
+            acnative.set_gemm_policy(acnative.GEMM_256x128)
+            a = fn()
+            acnative.set_gemm_policy(acnative.GEMM_AUTO)
+            b = fn()
+        finally:
+            acnative.set_gemm_policy(acnative.GEMM_AUTO)
+        return a, b
+
+    Zs, _ = clustered_embeddings(28, 784, 128, 4, salt=58)
+    pk = acnative.pack_images(torch.from_numpy(Zs).to(dev))
+    a, b = both(lambda: acnative.pair_block(pk, pk))
+    assert torch.isfinite(a.view(torch.float32)).all() and torch.equal(a, b)
+    # (the two kernels cut the triangle into different tiles, so a slice of one holds other cells than a slice of the
+    # other: what must agree is the MIN over the slices - and it must be the whole)
+    wa = [both(lambda r=r: acnative.pair_block(pk, pk, part=r, nparts=3)) for r in range(3)]
+    assert torch.equal(torch.stack([x[0].view(torch.float32) for x in wa]).min(0)[0],
+                       torch.stack([x[1].view(torch.float32) for x in wa]).min(0)[0])
+    assert torch.equal(torch.stack([x[1].view(torch.float32) for x in wa]).min(0)[0], b.view(torch.float32))
+    for (n, P, D, salt) in [(9, 100, 64, 61), (7, 67, 96, 62), (11, 130, 256, 63), (3, 784, 640, 64), (1, 784, 64, 65)]:
+        Zs, _ = clustered_embeddings(n, P, D, 3, salt=salt)
+        pk = acnative.pack_images(torch.from_numpy(Zs).to(dev))
+        a, b = both(lambda: acnative.pair_block(pk, pk))
+        assert torch.equal(a, b), (n, P, D)
+        for na in (1, n // 2):
+            if na < 1 or na >= n:
+                continue
+            A, B = pk.slice(0, na), pk.slice(na, n)
+            (a1, a2), (b1, b2) = both(lambda: acnative.pair_block(A, B, two_way=True))
+            assert torch.equal(a1, b1) and torch.equal(a2, b2), (n, na, P, D)
+            a, b = both(lambda: acnative.pair_block(B, A))
+            assert torch.equal(a, b), (n, na, P, D)
+
+
 def test_unknown_policy_is_rejected():
     import acnative
     with pytest.raises(RuntimeError, match="unknown policy"):

@@ -76,6 +76,24 @@ def test_best_map_matches_oracle():
         assert np.array_equal(best_map(L1, L2), ref(L1, L2))
 
 
+def test_label_encoding_and_micro_f1_equal_sklearn():
+    """clustering.encode_labels / micro_f1 replace sklearn's LabelEncoder / f1_score(average="micro") (what the reference
+    calls, examples/test.py:190-191, 220) on the scoring path: same ids, same score - also when a predicted id never
+    occurs in the truth, for one class, and for strings that sort unlike they were met."""
+    from sklearn import metrics
+    from sklearn.preprocessing import LabelEncoder
+    from patchcore.clustering import encode_labels, micro_f1
+    rng = np.random.default_rng(3)
+    for names in (["good", "crack", "good", "broken_large", "crack"], ["b"] * 4, ["z", "a", "m", "a"], []):
+        ref = LabelEncoder().fit_transform(names) if names else np.zeros(0, dtype=int)
+        assert np.array_equal(encode_labels(names), ref)
+    for k_true, k_pred, n in ((4, 4, 83), (6, 9, 160), (2, 3, 42), (1, 1, 5), (3, 3, 1)):
+        for _ in range(20):
+            label, predict = rng.integers(0, k_true, n), rng.integers(0, k_pred, n)
+            assert abs(micro_f1(label, predict) - metrics.f1_score(label, predict, average="micro")) <= 1e-15
+    assert micro_f1(np.array([0, 1, 2]), np.array([1, 2, 0])) == 0.0
+
+
 def test_shard_bounds_and_bank():
     from patchcore.pipeline import shard_bounds, select_bank
     assert shard_bounds(83, 8) == [(0, 11), (11, 22), (22, 33), (33, 44), (44, 55), (55, 66), (66, 77), (77, 83)]
