@@ -89,40 +89,64 @@ __host__ __device__ inline int tri_rows_before(int p, int Tn) {
 }
 // Linear order made for the L2, as gemm_hl2.h's: groups of G tile rows; inside a group the ACTUAL column runs slowest
 // and the row fastest, so that a contiguous run of the order (what one XCD works on at a time) covers G row panels and
-// the few column panels they share.  (This runs once per tile on the scalar unit, between two tiles of a persistent
-// workgroup, with the MFMA pipe idle: kept short - 32-bit, one square root, no division but by constants.)
-__device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn) {
-  // row p with F(p) <= lin < F(p + 1): F(p) = p (Tn + 1) - (2/3) p^2 - {0, 1/3, 1/3}[p % 3], so the root of the
-  // quadratic is within a row of the answer (single precision is enough: the loops below settle the last step)
-  int tn1 = Tn + 1;
-  asm volatile("" : "+s"(tn1));                         // (rebuilt per tile: hoisted out of the tile loop it is spilled)
-  const float t = (float)tn1;
-  int p = (int)(0.75f * (t - sqrtf(fmaxf(t * t - (8.0f / 3.0f) * (float)lin, 0.0f))));
-  p = max(0, min(p, Tm - 1));
-  while (p > 0 && tri_rows_before(p, Tn) > lin) --p;
-  while (p + 1 < Tm && tri_rows_before(p + 1, Tn) <= lin) ++p;
-  const int p0 = p - p % G, gsz = min(G, Tm - p0);
-  int w = lin - tri_rows_before(p0, Tn);                // index inside the group
-  int c = tri_c0(p0);
-  const int c_full = tri_c0(p0 + gsz - 1);              // from this column on every row of the group is valid
-  int r = 0;
-  for (;;) {                                            // ragged head: at most 4 (G - 1) / 3 + 1 columns
-    if (c >= c_full) { const int q = w / gsz; c = c_full + q; r = w - q * gsz; break; }
-    const int v = min(gsz, (3 * c + 2) / 4 - p0 + 1);   // rows p0 .. with c0(row) <= c
-    if (w < v) { r = w; break; }
+// the few column panels they share.
+// This runs once per tile on the scalar unit, between two tiles of a persistent workgroup, with the MFMA pipe idle -
+// and hipcc keeps ~150 scalar registers of this kernel spilled in vector lanes, so every operand costs a v_readlane.
+// The group of the PREVIOUS tile is therefore remembered (TriCache): a workgroup's next tile is ~32 positions further on
+// in the same XCD's run and nearly always in the same group of ~G Tn tiles, where the answer is one subtraction and
+// one division by the group's row count; the square root and the search run on a group change only.
+struct TriCache {
+  int lo = 0, n = 0;            // linear ids [lo, lo + n) are the cached group's tiles (n = 0: nothing cached)
+  int p0 = 0, gsz = 1;          // its first tile row, its rows
+  int c_head = 0, c_full = 0;   // its first column; from c_full on every row of the group is valid
+  int head = 0;                 // tiles in the ragged head (columns c_head .. c_full - 1)
+  float inv = 1.f;              // 1 / gsz
+};
+__device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn, TriCache& tc) {
+  if ((unsigned)(lin - tc.lo) >= (unsigned)tc.n) {
+    // row p with F(p) <= lin < F(p + 1): F(p) = p (Tn + 1) - (2/3) p^2 - {0, 1/3, 1/3}[p % 3], so the root of the
+    // quadratic is within a row of the answer (single precision is enough: the loops below settle the last step)
+    const float t = (float)(Tn + 1);
+    int p = (int)(0.75f * (t - sqrtf(fmaxf(t * t - (8.0f / 3.0f) * (float)lin, 0.0f))));
+    p = max(0, min(p, Tm - 1));
+    while (p > 0 && tri_rows_before(p, Tn) > lin) --p;
+    while (p + 1 < Tm && tri_rows_before(p + 1, Tn) <= lin) ++p;
+    tc.p0 = p - p % G;
+    tc.gsz = min(G, Tm - tc.p0);
+    tc.lo = tri_rows_before(tc.p0, Tn);
+    tc.n = tri_rows_before(tc.p0 + tc.gsz, Tn) - tc.lo;
+    tc.c_head = tri_c0(tc.p0);
+    tc.c_full = tri_c0(tc.p0 + tc.gsz - 1);
+    tc.head = 0;
+    for (int c = tc.c_head; c < tc.c_full; ++c) tc.head += min(tc.gsz, (3 * c + 2) / 4 - tc.p0 + 1);   // <= 4 (G - 1) / 3 + 1 columns
+    tc.inv = 1.0f / (float)tc.gsz;
+  }
+  int w = lin - tc.lo;                                   // index inside the group
+  if (w >= tc.head) {                                    // full columns: gsz tiles each
+    w -= tc.head;
+    const int q = (int)(((float)w + 0.5f) * tc.inv);     // w / gsz, exact: gsz <= G is small, w < 2^22
+    tn = tc.c_full + q;
+    tm = tc.p0 + (w - q * tc.gsz);
+    return;
+  }
+  int c = tc.c_head;
+  for (;;) {                                             // ragged head: column c holds the rows p0 .. with c0(row) <= c
+    const int v = min(tc.gsz, (3 * c + 2) / 4 - tc.p0 + 1);
+    if (w < v) break;
     w -= v;
     ++c;
   }
-  tm = p0 + r;
+  tm = tc.p0 + w;
   tn = c;
 }
 
 // `total`: the launch's tile count (the launcher passes it: tri_rows_before(Tm, Tn) for a symmetric problem)
 template <class Epi>
-__device__ inline void tile_of(int id, int total, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn) {
+__device__ inline void tile_of(int id, int total, int tiles_m, int tiles_n, int group_m, const Epi& epi, int& tm, int& tn,
+                               TriCache& tc) {
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {
-      tri_tile(gemm2::xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m, tm, tn);
+      tri_tile(gemm2::xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m, tm, tn, tc);
       return;
     }
   }
@@ -189,6 +213,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   auto resolve = [&](unsigned ticket) { *lds_next = gemm2::queue_resolve(queue, ticket, id_lo, id_hi); };
 
   int id, tm = 0, tn = 0;
+  TriCache tcache;
   if (queue) {
     if (tid == 0) resolve(take());
     __syncthreads();
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
     if (nk > 2) dmaB(2, 2);
   };
-  tile_of(id, total, tiles_m, tiles_n, group_m, epi, tm, tn);            // block-uniform
+  tile_of(id, total, tiles_m, tiles_n, group_m, epi, tm, tn, tcache);            // block-uniform
   m0 = tm * BM;
   n0 = tn * BN;
   issue_prologue();
@@ -374,7 +399,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     if (queue) {
       next = __builtin_amdgcn_readfirstlane(*lds_next);        // block-uniform: the tile arithmetic stays scalar
       if (next >= 0) {
-        tile_of(next, total, tiles_m, tiles_n, group_m, epi, tm, tn);
+        tile_of(next, total, tiles_m, tiles_n, group_m, epi, tm, tn, tcache);
         m0 = tm * BM;
         n0 = tn * BN;
         early = fast_cur;                                      // no wave of this tile touches the ring any more

@@ -84,9 +84,12 @@ def _truth_w(Zq_rows, Zk, reduce, skip=None, chunk=48):
 
 
 # ------------------------------------------------------------------------------------------------ config 2
-def test_config2_whole_alpha_matrix_against_oracle(dev, core):
-    """BASELINE config 2 (the bench workload): every one of the 83 x 784 alpha values, X and the three scores."""
-    from oracle import vit as ovit, aggregate as oagg, alpha as oalpha, cluster as ocluster
+def test_config2_whole_alpha_matrix_against_oracle(dev, core, config2_oracle):
+    """BASELINE config 2 (the bench workload): every one of the 83 x 784 alpha values, X and the three scores.  The oracle
+    leg (a minute of host time) was started as a CPU-only child process when the session began (conftest.py,
+    tests/_config2_oracle.py) and is collected here; it counts only if the child's weights ARE the device's weights."""
+    import _config2_oracle as oleg
+    from oracle import cluster as ocluster
     from patchcore.pipeline import HipOps, run_category
     from patchcore.datasets import synthetic
     from patchcore.clustering import cluster_metrics_from_pdist
@@ -99,19 +102,23 @@ def test_config2_whole_alpha_matrix_against_oracle(dev, core):
     torch.cuda.synchronize()
 
     t0 = time.perf_counter()
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(32, os.cpu_count() or 1))          # the box's default (one per hardware thread) is 4x slower here
     sd = {k: v.detach().cpu() for k, v in core.backbone.state_dict().items()}
-    Zs = []
-    for i in range(n):                                           # the reference's batch size 1 (main.py:213)
-        taps = ovit.forward_taps(sd, images[i:i + 1], taps=(10, 11))
-        Zs.append(oagg.aggregate([taps[10], taps[11]], 3, 2048, 4096)[0])
-    Zr = torch.stack(Zs).reshape(n, P, D)
-    w_ref = oalpha.weights_unsupervised(Zr)                      # utils.py:222-227 for every image
-    a64 = torch.cat([oalpha.alpha_from_weights(w, 1.0, 1) for w in w_ref], dim=0)     # utils.py:240-257
-    a_ref, X_ref = oalpha.weighted_average(a64, Zr)
-    torch.set_num_threads(threads)
-    print("oracle at N=83: %.1f s of host time" % (time.perf_counter() - t0))
+    res = config2_oracle()
+    if res is not None and not np.array_equal(res["weight_sums"], oleg.weight_sums(sd).numpy()):
+        res = None                                               # (cannot happen with the seeded init: then nothing of it is used)
+    if res is None:                                              # no child (a single-test run on a box without one): here and now
+        threads = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))      # the box's default (one per hardware thread) is 4x slower here
+        res = oleg.compute(sd, images, labels)
+        torch.set_num_threads(threads)
+        print("oracle at N=83 computed inside the test: %.1f s of host time" % (time.perf_counter() - t0))
+    else:
+        print("oracle at N=83: %.1f s of host time in the child process, %.1f s waited for here"
+              % (float(res["seconds"][0]), time.perf_counter() - t0))
+    Zr, w_ref = torch.from_numpy(res["Z"]), torch.from_numpy(res["w"])
+    a_ref, X_ref = torch.from_numpy(res["alpha"]), res["X"]
+    rn, ra, rf = (float(v) for v in res["scores"])
+    rlabel = res["label"]
 
     a = out["alpha"].cpu().numpy()
     assert a.shape == (n, 1, P)
@@ -122,7 +129,6 @@ def test_config2_whole_alpha_matrix_against_oracle(dev, core):
     # w itself: the oracle's fp32 cdist and the split-fp16 kernel are each within W_TOL of the float64 truth
     assert (out["w_loc"].cpu() - w_ref).abs().max().item() <= 2 * W_TOL
     nmi, ari, f1, label, predict = cluster_metrics_from_pdist(out["pdist"], labels)
-    rn, ra, rf, rlabel, rpredict = ocluster.calculate_metrics(X_ref, labels)
     print("N=83: alpha max rel err %.2e, X max abs err %.2e, NMI/ARI/F1 %.4f/%.4f/%.4f (oracle %.4f/%.4f/%.4f)"
           % (np.max(np.abs(a - a_ref.numpy()) / np.maximum(a_ref.numpy(), 1e-12)), np.max(np.abs(out["X"] - X_ref)),
              nmi, ari, f1, rn, ra, rf))
