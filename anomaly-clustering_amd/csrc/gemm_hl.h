@@ -42,7 +42,7 @@ constexpr int FLUSH_STAGES = 16;          // two-level sum: MFMA accumulator flu
 #define AC_XCD_WINDOW_TRI 0
 #endif
 template <int W>
-__device__ inline int xcd_lin(int id, long long total) {
+__host__ __device__ inline int xcd_lin(int id, long long total) {
   const int xcd = id & 7, slot = id >> 3;
   if constexpr (W > 0) {
     const long long full = total / (8 * W) * (8 * W);

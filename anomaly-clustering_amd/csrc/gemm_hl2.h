@@ -153,7 +153,7 @@ __host__ __device__ inline long long tri_rows_before(int p, int Tn) { return (lo
 // first; a window of folded columns then touched 2G - 2 + 32/G different column panels.  Same-box A/B,
 // profiles/r02_raster_ab.txt: -2 % time, G = 6 best.)
 // Equal work per XCD and per GPU slice needs no folding: the order is cut into equal runs by tile count.
-__device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn) {
+__host__ __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn) {
   // row p with F(p) <= lin < F(p + 1): root of p^2 - (Tn + 1) p + lin = 0, then the group it belongs to
   const double b = (double)Tn + 1.0;
   int p = (int)((b - sqrt(fmax(b * b - 4.0 * (double)lin, 0.0))) * 0.5);

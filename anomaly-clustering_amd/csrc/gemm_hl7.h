@@ -102,7 +102,7 @@ struct TriCache {
   int head = 0;                 // tiles in the ragged head (columns c_head .. c_full - 1)
   float inv = 1.f;              // 1 / gsz
 };
-__device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn, TriCache& tc) {
+__host__ __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm, int& tn, TriCache& tc) {
   if ((unsigned)(lin - tc.lo) >= (unsigned)tc.n) {
     // row p with F(p) <= lin < F(p + 1): F(p) = p (Tn + 1) - (2/3) p^2 - {0, 1/3, 1/3}[p % 3], so the root of the
     // quadratic is within a row of the answer (single precision is enough: the loops below settle the last step)

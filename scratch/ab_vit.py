@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Same-box, same-process A/B of builds of libac_hip.so on ONE ViT-B/8 block (ac_vit_block) at a batch of images.
 
-    python scratch/ab_vit.py [--images 83] [--rounds 7] name=path/to/lib.so name2=path2 ...
+    python scratch/ab_vit.py [--images 83] [--rounds 7] name=path/to/lib.so name2=path2[@policy] ...
+
+`@policy`: ac_set_gemm_policy(policy) on that library before its runs (1 / 2 pin the 256x128 / 256x256 kernel; 101 ... 109
+select a superseded GEMM generation of a `build.py --experimental` library, e.g. 101 = round 1's 128x128 tiles on 4 waves with
+64 KB of LDS: TWO co-resident workgroups per CU).
 
 Random block weights (packed by each library itself), random residual stream; interleaved rounds; prints median /
 min time of the block per library and whether the outputs are bit-equal to the first library's."""
@@ -44,7 +48,12 @@ def main():
     libs = []
     for spec in a.libs:
         name, path = spec.split("=", 1)
+        policy = None
+        if "@" in path:
+            path, policy = path.rsplit("@", 1)
         lib = bind(path)
+        if policy is not None:
+            assert lib.ac_set_gemm_policy(int(policy)) == 0, lib.ac_last_error()
         keep, w = {}, BlockWeights()
         for k, m in mats.items():
             out = torch.empty((m.shape[0], m.shape[1] * 4), dtype=torch.uint8, device=dev)

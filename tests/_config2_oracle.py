@@ -19,9 +19,12 @@ for p in (ROOT, os.path.join(ROOT, "anomaly-clustering_amd", "models")):
 
 
 def weight_sums(sd):
-    """One float64 number per tensor, in key order: equal weights <=> equal lists (the init is seeded, bit-reproducible)."""
+    """One number per tensor, in key order: the sum of the fp32 BIT PATTERNS as integers - exact and independent of the
+    order of summation (a floating-point sum changes with the thread count of the process that forms it).  Equal weights
+    <=> equal lists (the init is seeded and bit-reproducible)."""
     import torch
-    return torch.tensor([float(v.detach().double().sum()) for _, v in sorted(sd.items())], dtype=torch.float64)
+    return torch.tensor([int(v.detach().float().contiguous().view(torch.int32).to(torch.int64).sum()) for _, v in sorted(sd.items())],
+                        dtype=torch.int64)
 
 
 def compute(sd, images, labels):
