@@ -26,18 +26,23 @@
 //     barrier (the one that retires the ring) also hands over the tile id;
 //   * a tile whose eight 64 x 96 blocks all reduce from registers (inside the problem, off the diagonal: 98 % of them at
 //     N = 83) gets its squared norms by DMA into a small LDS buffer together with its first stage, so its epilogue issues no
-//     global load - and the first stages of the NEXT tile are issued before that epilogue starts: the 5 us cold start of a
-//     tile's operand stream runs under the reductions of the tile before it.
+//     global load, and the DMA-issuing waves start the next tile's stream right behind their own reductions, without a
+//     barrier;
+//   * the group of the previous tile is cached, so the scalar tile arithmetic between two tiles is a subtraction and a
+//     division instead of a square root and a search (6.9k -> 2.1k cycles per tile).
 //
 // Arithmetic: per output element the same chain as gemm_hl2.h's FLUSH kernel - stages in k order, passes hi*lo, lo*hi,
 // hi*hi, the MFMA accumulator added into the second one every 16 stages - so the two kernels agree to the bit
 // (tests/test_gemm_generations_gpu.py::test_all_pairs_tiles_agree_bitwise, scratch/ab_pairmin.py).
 //
-// Measured (MI355X, N = 83, same box, interleaved; profiles/r05_allpairs_256x192_ab.txt): -3.6 ... -4.5 % against the
-// 256x128 kernel; fabric traffic 88.6 -> 67.3 GB per launch, MFMA-pipe occupancy 73.5 -> 76.5 % at the SAME 1.63 GHz (the
-// package stays at its power cap: the joules the operand stream no longer takes go into more MFMAs per second, not into
-// clock).  Not kept (scratch/exp_g7_stagger_and_knobs.patch): a half-stage stagger of waves 4-7 (+10 ... +18 %), DMA issue
-// from all eight waves (+8 %), priority variants (0 ... +1 %).
+// Measured (MI355X, N = 83, same box, interleaved; profiles/r05_allpairs_256x192_ab.txt): -3.6 ... -4.7 % against the
+// 256x128 kernel; fabric traffic 88 -> 67 ... 75 GB per launch, MFMA-pipe occupancy 73.5 -> 76.5 ... 78.5 % at the same or a
+// slightly LOWER clock (the package stays at its power cap: the joules the operand stream no longer takes go into more
+// MFMAs per second, not into clock - and every cycle the tile transition gave up after the first build came back as
+// clock: early ticket, LDS norms, cached tile arithmetic together -3 % cycles, -0.3 % time).  Not kept
+// (scratch/exp_g7_stagger_and_knobs.patch, scratch/exp_g7_early_prologue.patch): a half-stage stagger of waves 4-7
+// (+10 ... +18 %), DMA issue from all eight waves (+8 %), priority variants (0 ... +1 %), the next tile's first stages
+// issued before the epilogue (equal time, +19 % fabric traffic).
 #pragma once
 #include "gemm_hl2.h"
 
@@ -229,13 +234,15 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   unsigned long long tt_pro = 0, tt_loop = 0, tt_vm = 0, tt_bar = 0, tt_epi = 0, tt_tiles = 0, tt_e1 = 0, tt_e2 = 0;
   const unsigned long long tt_start = __builtin_readcyclecounter();
 #endif
-  // The first stages of a tile - A(0) B(0) A(1) B(1) B(2), in that order - are issued BEFORE the epilogue of the tile in
-  // front of it whenever that epilogue works from registers alone (a "fast" tile: every 64 x 96 block inside the problem
-  // and off the diagonal), so the cold start of a tile's operand stream (5 us) runs under the previous tile's reductions.
-  // A fast tile's squared norms travel the same way, FIRST in the queue (waves 0 and 1, one DMA instruction each: 256
-  // row norms, 192 column norms) into one of two small LDS buffers: its epilogue then issues no global load at all - a
-  // wave's memory operations retire in order, so norm loads issued behind the next tile's 34 transfers would return
-  // microseconds late, and issued in front of them they cost 22 registers this kernel does not have.
+  // The first stages of a tile - A(0) B(0) A(1) B(1) B(2), in that order - go out as soon as the wave has finished the
+  // epilogue of the tile in front of it.  A "fast" tile (every 64 x 96 block inside the problem and off the diagonal: its
+  // epilogue works from registers) gets its squared norms the same way, FIRST in the queue (waves 0 and 1, one DMA
+  // instruction each: 256 row norms, 192 column norms) into one of two small LDS buffers: its epilogue then issues no
+  // global load, and behind a fast tile the DMA-issuing waves need no barrier before they start the next tile's stream.
+  // (Measured and NOT kept, round 5: issuing these transfers BEFORE the epilogue - the cold start of a tile then runs under
+  // the reductions of the tile before it, -1.2 % cycles per tile - raises the L2-miss traffic of the launch from 75 to 89 GB
+  // (the L2 hit rate falls from 76.8 to 72.1 %: the first stages are fetched out of step with the tiles that share their
+  // panels), the clock follows it down (1594 -> 1581 MHz) and the time does not move: profiles/r05_allpairs_early_prologue_pmc.txt.)
   bool fast_next = false;      // the tile whose prologue was issued last is fast (its norms are in LDS buffer norm_par)
   int norm_par = 1;
   auto issue_prologue = [&]() {
@@ -255,13 +262,11 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   m0 = tm * BM;
   n0 = tn * BN;
   issue_prologue();
-  bool counted = true;
-  int n_behind = 0;
   for (;;) {
 #ifdef AC_G7_TIMING
     const unsigned long long tt_a = __builtin_readcyclecounter();
 #endif
-    const int m0c = m0, n0c = n0;                                 // this tile (m0, n0 move on to the next one early)
+    const int m0c = m0, n0c = n0;                                 // this tile (m0, n0 move on to the next one before its epilogue)
     const bool fast_cur = fast_next;                              // ... is fast, its norms are in LDS buffer norm_cur
     const int norm_cur = norm_par;
     f32x4 acc[4][NTN], tot[4][NTN];
@@ -272,21 +277,11 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[mi][ni][i] = 0.f; tot[mi][ni][i] = 0.f; }
 
-    // the first two of the five prologue transfers must have landed (only waves that issued any wait).  Behind them
-    // in the wave's queue: the other three and - early prologue - the epilogue's atomicMins, which take microseconds
-    // to retire under load and need not be waited for.
+    // the first two of the five prologue transfers must have landed (only the waves that issued them wait)
     if (loader) {
-      constexpr int REST = BM / (8 * LW) + 2 * (BN / (8 * LW));      // A(1) B(1) B(2)
-      if (nk <= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST) : "memory");
-      else switch (n_behind) {
-        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 2) : "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 3) : "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 4) : "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 5) : "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REST + 6) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      }
+      if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * LW) + 2 * (BN / (8 * LW))) : "memory");      // A(1) B(1) B(2) may fly
+      else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * LW) + BN / (8 * LW)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     barrier();
     half8 ah[4], al[4], bh, bl;
@@ -377,7 +372,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     // EVERY lane consumes the ticket register here: hipcc's wait-count pass merges paths, and with the atomic and its
     // use in two separate `tid == 0` branches it would otherwise believe the register still pending all round the
     // tile loop and put an s_waitcnt vmcnt(0) in front of every reuse of that register - between the DMA bursts of the
-    // early prologue, for one.
+    // next tile's prologue, for one.
     asm volatile("" : "+v"(ticket));
     if (queue && tid == 0) resolve(ticket);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -395,15 +390,12 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
         for (int i = 0; i < 4; ++i) acc[mi][ni][i] += tot[mi][ni][i];
     const int m_wave = m0c + wm * 64, n_wave = n0c + wn * (NTN * 16);
     int next = -1;
-    bool early = false;
     if (queue) {
       next = __builtin_amdgcn_readfirstlane(*lds_next);        // block-uniform: the tile arithmetic stays scalar
       if (next >= 0) {
         tile_of(next, total, tiles_m, tiles_n, group_m, epi, tm, tn, tcache);
         m0 = tm * BM;
         n0 = tn * BN;
-        early = fast_cur;                                      // no wave of this tile touches the ring any more
-        if (early) issue_prologue();
       }
     }
 #ifdef AC_G7_TIMING
@@ -416,7 +408,6 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 #endif
     // ---- epilogue: the wave's 64 x 96 block at rows m_wave, columns n_wave
     const bool sym = epi.symmetric;
-    int n_atomics = 0;
     // symmetric problem: only elements with row <= column are used, each reduced in both directions (gemm_hl2.h).
     // A block wholly above the diagonal and inside the problem: both reductions from registers (epi.fast_wide);
     // otherwise the general code on a 64 x 64 and a 64 x 32 piece, per-element diagonal mask where a piece crosses it.
@@ -429,7 +420,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(nb + wm * 64 + 16 * mi + 4 * (lane >> 4));
 #pragma unroll
       for (int ni = 0; ni < NTN; ++ni) qs[ni] = nb[256 + wn * (NTN * 16) + 16 * ni + (lane & 15)];
-      n_atomics = epi.template fast_reduce<NTN>(acc, ks, qs, m_wave, n_wave, lane, sym || epi.two_way);
+      epi.template fast_reduce<NTN>(acc, ks, qs, m_wave, n_wave, lane, sym || epi.two_way);
     } else if (!below) {
       const bool both = sym || epi.two_way;
       const bool clear = !sym || m_wave + 63 <= n_wave;
@@ -462,13 +453,11 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     }
 #endif
     if (next < 0) break;                           // every queue is exhausted (or: one workgroup per tile)
-    if (!early) {                                  // the general epilogue used the ring as scratch: everyone is out of it
+    if (!fast_cur) {                               // the general epilogue used the ring as scratch: everyone must be out of it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       barrier();
-      issue_prologue();
     }
-    counted = !early;
-    n_behind = n_atomics;                          // early: that many atomicMins were issued behind the DMA
+    issue_prologue();
     id = next;
   }
 }
