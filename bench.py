@@ -679,7 +679,7 @@ def main():
                                     "images_per_sec": len(it["labels"]) / t} for it, t in zip(items, per_cat)]
         elif len(items) > 1:                 # one job: the categories share ViT batches, no per-category clock exists
             out["per_category"] = [{"category": it["category"], "n": len(it["labels"])} for it in items]
-        if can_feed:
+        if can_feed and steps >= 2:                         # (a one-step run is a functional check: nothing to compare)
             k_res = steps                                   # as many steps as the timed run: the two figures are compared
             el, _ = timed(k_res)
             out["images_resident"] = {"value": n_total * k_res / el, "ms_per_step": 1e3 * el / k_res, "steps": k_res,

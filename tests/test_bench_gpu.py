@@ -67,7 +67,7 @@ def _check_all15(d, mode):
     assert 0 < roof["frac"] < (2 / 3 if mode == "unsupervised" else 1.0)
     # the committed PMC summary of THIS workload (profiles/r03_config*_pmc.json) supplies the HBM-side bytes
     assert roof["traffic"] is not None and roof["traffic"] > 0 and roof["traffic_source"].startswith("profiles/")
-    assert set(d["stage_ms"]) >= {"embed", "pair_min_dist", "pdist"} and d["images_resident"]["value"] > 0
+    assert set(d["stage_ms"]) >= {"embed", "pair_min_dist", "pdist"}
     assert "pinned host memory" in d["config"]["input"]       # `value` starts at the H2D copy
 
 
@@ -75,13 +75,13 @@ def _check_all15(d, mode):
 def test_bench_config_3_all_fifteen_categories(schedule):
     """BASELINE config 3 end to end through bench.py on one GPU (the 8-GPU run is the driver's): ~5 s.  The 15 categories
     as one job (default), one after another (the reference's loop), whole categories per GPU (one GPU: all on it)."""
-    d = _bench("--config", "3", "--gpus", "1", "--no-cpu-baseline", "--steps", "1", "--category-schedule", schedule)
+    d = _bench("--config", "3", "--gpus", "1", "--no-cpu-baseline", "--steps", "1", "--warmup", "0", "--category-schedule", schedule)
     assert d["config"]["category_schedule"] == schedule
     _check_all15(d, "unsupervised")
 
 
 def test_bench_config_4_supervised():
-    _check_all15(_bench("--config", "4", "--gpus", "1", "--no-cpu-baseline", "--steps", "1"), "supervised")
+    _check_all15(_bench("--config", "4", "--gpus", "1", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"), "supervised")
 
 
 @pytest.mark.parametrize("ranks,extra", [(4, ()), (2, ("--config", "3"))])
@@ -93,7 +93,7 @@ def test_bench_rehearsal_of_the_multi_rank_run_on_one_gpu(ranks, extra):
     common = ("--no-cpu-baseline", "--steps", "1", "--warmup", "0") + tuple(extra)
     # the one-rank run it is compared with: config 3's is the run test_bench_config_3[pipeline] makes (the scores of a step do
     # not depend on warm-up), config 2's is made here
-    one = (_bench("--config", "3", "--gpus", "1", "--no-cpu-baseline", "--steps", "1", "--category-schedule", "pipeline")
+    one = (_bench("--config", "3", "--gpus", "1", "--no-cpu-baseline", "--steps", "1", "--warmup", "0", "--category-schedule", "pipeline")
            if extra else _bench("--gpus", "1", *common))
     d = _bench("--gpus", str(ranks), "--rehearse-on-one-gpu", *common)
     assert REQUIRED <= set(d) and d["n_gpus"] == ranks and "rehearsal" in d and "rehearsal" not in one
