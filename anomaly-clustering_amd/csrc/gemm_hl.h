@@ -54,15 +54,24 @@ __host__ __device__ inline int xcd_lin(int id, long long total) {
   }
 }
 
-__device__ inline void raster(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+template <int W>
+__device__ inline void raster_w(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
   int total = tiles_m * tiles_n;
-  int lin = xcd_lin<AC_XCD_WINDOW_RECT>(id, total);
+  int lin = xcd_lin<W>(id, total);
   int per_group = group_m * tiles_n;
   int g = lin / per_group, within = lin - g * per_group;
   int first = g * group_m;
   int gsz = min(group_m, tiles_m - first);
   tn = within / gsz;
   tm = first + (within - tn * gsz);
+}
+__device__ inline void raster(int id, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+  raster_w<AC_XCD_WINDOW_RECT>(id, tiles_m, tiles_n, group_m, tm, tn);
+}
+// the same with the XCD order chosen at run time (gemm_hl7.h): windowed (W = 32) or one contiguous eighth per XCD
+__device__ inline void raster_rt(int id, int tiles_m, int tiles_n, int group_m, bool windowed, int& tm, int& tn) {
+  if (windowed) raster_w<32>(id, tiles_m, tiles_n, group_m, tm, tn);
+  else raster_w<0>(id, tiles_m, tiles_n, group_m, tm, tn);
 }
 
 // Register image of one wave's 64x64 accumulator, for the two fp16 MFMA shapes.  Epilogues are

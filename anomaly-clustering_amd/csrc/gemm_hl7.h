@@ -65,6 +65,14 @@ constexpr int NORM_BYTES = 2048, LDS_NORMS = 2 * NORM_BYTES;
 constexpr int LDS_EXTRA = LDS_NORMS + 16;
 constexpr int FLUSH_STAGES = gemm::FLUSH_STAGES;
 
+// XCD order of a RECTANGLE's tiles (two-way and one-way blocks; gemm_hl.h xcd_lin): windows of 32 tiles dealt to the XCDs in turn
+// (the 8 XCDs side by side on neighbouring windows) for SMALL rectangles, one contiguous eighth of the grouped order per XCD
+// for LARGE ones.  Round 4 had measured the windows best at every size for the 256x128 kernel.  For this kernel (round 5,
+// profiles/r05_allpairs_rect_xcd_order_ab.txt, two-way blocks of n x n images, same box): windows -3.4 % at 11 x 11, -2.4 % at
+// 21 x 21, -0.5 % at 42 x 42 - and +2.4 % at 100 x 100, +3.4 % at 300 x 300, where the L2 hit rate of the launch is 35 % with
+// windows and 79 % without (fabric traffic 596 against 189 GB at 100 x 100).  The launcher switches at 160 tiles per CU; it
+// travels in bit 16 of the group argument.  (-DAC_G7_WINDOW_RECT=0 / 32 pins one order for A/B builds.)
+constexpr int RECT_WINDOW_TILES_PER_CU = 160;
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE7=1 no DMA in the k loop, 2 no fragment reads in the
 // k loop, 4 no MFMAs (combinable).  0 in every shipped build.
 #ifndef AC_ABLATE7
@@ -151,11 +159,11 @@ __device__ inline void tile_of(int id, int total, int tiles_m, int tiles_n, int 
                                TriCache& tc) {
   if constexpr (EpiTraits<Epi>::kSymmetric) {
     if (epi.symmetric) {
-      tri_tile(gemm2::xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m, tm, tn, tc);
+      tri_tile(gemm2::xcd_chunk_lin(id, total), tiles_m, tiles_n, group_m & 0xffff, tm, tn, tc);
       return;
     }
   }
-  gemm::raster(id, tiles_m, tiles_n, group_m, tm, tn);
+  gemm::raster_rt(id, tiles_m, tiles_n, group_m & 0xffff, (group_m >> 16) & 1, tm, tn);
 }
 
 template <class Epi>
@@ -469,7 +477,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl7: K=%d must be a positive multiple of 32", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl7: bad part %d/%d", part, nparts);
-  if (group_m < 1) return ac_fail(AC_EINVAL, "gemm_hl7: group_m=%d must be positive", group_m);
+  if (group_m < 1 || group_m > 0xffff) return ac_fail(AC_EINVAL, "gemm_hl7: group_m=%d out of range", group_m);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   long long total = (long long)tiles_m * tiles_n;
   if (total > 0x7fffffffLL) return ac_fail(AC_EINVAL, "gemm_hl7: grid too large");
@@ -489,9 +497,14 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
     if (int rc = gemm2::queue_acquire(&queue, stream)) return rc;
     grid = n_cu;
   }
+#ifdef AC_G7_WINDOW_RECT
+  const bool windowed = AC_G7_WINDOW_RECT != 0;
+#else
+  const bool windowed = hi - lo < (long long)RECT_WINDOW_TILES_PER_CU * n_cu;
+#endif
   hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA, stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
-                     group_m, (int)lo, (int)hi, (int)total, epi, queue);
+                     group_m | (windowed ? 1 << 16 : 0), (int)lo, (int)hi, (int)total, epi, queue);
   return ac_check_launch("gemm_hl7");
 }
 

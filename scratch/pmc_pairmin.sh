@@ -1,5 +1,5 @@
 # gpurun -- bash scratch/pmc_pairmin.sh <tag> <lib> [N]   : L2 hit rate, fabric bytes, clock and MFMA-pipe occupancy of the
-# symmetric all-pairs launch of ONE build of the library (scratch/ab_pairmin.py as the program; --pmc passes carry
+# symmetric all-pairs launch (PM_ARGS="--two-way Q": a two-way block of N x Q images instead) of ONE build of the library (scratch/ab_pairmin.py as the program; --pmc passes carry
 # --kernel-trace only, the program itself after `--`).  Output: gpurun_out/pmc_pairmin_<tag>/*.csv
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -8,7 +8,7 @@ O=$R/gpurun_out/pmc_pairmin_$TAG
 rm -rf $O; mkdir -p $O
 for p in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum"; do
   name=$(echo $p | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $p --kernel-trace --output-format csv -d $O/$name -- python3 $R/scratch/ab_pairmin.py --n $N --rounds 3 --no-vendor x=$LIB > $O/$name.log 2>&1
+  timeout 300 rocprofv3 --pmc $p --kernel-trace --output-format csv -d $O/$name -- python3 $R/scratch/ab_pairmin.py --n $N ${PM_ARGS:-} --rounds 3 --no-vendor x=$LIB > $O/$name.log 2>&1
   f=$(find $O/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $O/$name.csv
   rm -rf $O/$name
