@@ -672,9 +672,10 @@ def main():
                             "measurement of %d GPUs" % (world, world))
     if not args.no_extras:
         per_cat, stages = [], {}
-        step(timings=stages, per_cat=per_cat)                   # one extra, untimed-for-the-metric step
-        out["stage_ms"] = {k: 1e3 * v for k, v in stages.items()}
-        if len(items) > 1 and not many:
+        if not (args.rehearse_on_one_gpu and world > 1):        # (ranks sharing one GPU: stage times would mean nothing)
+            step(timings=stages, per_cat=per_cat)               # one extra, untimed-for-the-metric step
+            out["stage_ms"] = {k: 1e3 * v for k, v in stages.items()}
+        if len(items) > 1 and not many and per_cat:
             out["per_category"] = [{"category": it["category"], "n": len(it["labels"]), "ms": 1e3 * t,
                                     "images_per_sec": len(it["labels"]) / t} for it, t in zip(items, per_cat)]
         elif len(items) > 1:                 # one job: the categories share ViT batches, no per-category clock exists
