@@ -5,7 +5,7 @@ the ViT taps instead of Z), then
   * alpha finite, positive, rows summing to 1,
   * w of three images (first block, a middle block, the last block) against the float64 brute force over all 9 999 other
     images (Z rebuilt from the taps chunk by chunk), gate 2e-5 as in tests/test_configs_full_gpu.py.
-Takes ~10 minutes of GPU time; prints a progress line a minute.  Writes gpurun_out/r04_verify_5b_n10000.json.
+Takes ~10 minutes of GPU time; prints a progress line a minute.  Writes gpurun_out/verify_5b_n10000.json (committed per round as profiles/rNN_verify_5b_n10000.json).
 
     python scratch/verify_5b_n10000.py [N]"""
 import json
@@ -83,7 +83,7 @@ def main():
     res.update({"w_checked_images": idx, "w_max_abs_err_vs_fp64": err, "w_mean": float(truth.mean()), "w_gate": 2e-5})
     print(json.dumps(res))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r04_verify_5b_n10000.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "verify_5b_n10000.json"), "w"), indent=1)
     ok = (abs(pairs - n * (n - 1.0)) < 1e-3 and res["alpha_finite"] and res["alpha_positive"] and res["alpha_row_sum_max_dev"] <= 1e-5
           and err <= 2e-5)
     sys.exit(0 if ok else 1)
