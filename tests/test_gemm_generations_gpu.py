@@ -62,7 +62,8 @@ def test_all_pairs_tiles_agree_bitwise(dev):
       * symmetric (triangle of tiles, persistent workgroups on the tile queues: 28 x 784 rows), whole and in 3 slices,
       * symmetric on shapes whose blocks straddle the diagonal and the image boundaries in every way (P = 100, 67, 130; K
         of 1, 2, 3, 8 stages: below one flush interval, and past it with P = 784 / D = 640: 20 stages),
-      * two-way and one-way rectangles with ragged edges, one-image blocks included."""
+      * two-way and one-way rectangles with ragged edges, one-image blocks included, and one rectangle large enough for
+        the second XCD order of the new kernel."""
     import acnative
     from _synth import clustered_embeddings
 
@@ -99,6 +100,15 @@ def test_all_pairs_tiles_agree_bitwise(dev):
             assert torch.equal(a1, b1) and torch.equal(a2, b2), (n, na, P, D)
             a, b = both(lambda: acnative.pair_block(B, A))
             assert torch.equal(a, b), (n, na, P, D)
+    # a rectangle LARGE enough for the other XCD order of the 256x192 kernel (gemm_hl7.h: windows of 32 tiles below 160 tiles
+    # per CU, one contiguous eighth per XCD above - 64 x 64 images are 196 x 262 = 51 352 tiles), two-way and one-way
+    Zs, _ = clustered_embeddings(128, 784, 64, 4, salt=67)
+    pk = acnative.pack_images(torch.from_numpy(Zs).to(dev))
+    A, B = pk.slice(0, 64), pk.slice(64, 128)
+    (a1, a2), (b1, b2) = both(lambda: acnative.pair_block(A, B, two_way=True))
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    a, b = both(lambda: acnative.pair_block(B, A))
+    assert torch.equal(a, b) and torch.isfinite(a.view(torch.float32)).all()
 
 
 def test_unknown_policy_is_rejected():
