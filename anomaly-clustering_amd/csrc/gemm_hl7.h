@@ -180,7 +180,6 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nk = K / BK;
-  const size_t ld = (size_t)K * 4;
 
   // DMA map (gemm_hl5.h's): a half-tile is 32 (A) / 24 (B) wave-instructions of 1 KB = 8 rows each, issued by waves
   // 0-3 only - the SIMD's arbiter serves its older wave first, so their issue stalls hide behind the partner's MFMAs.
