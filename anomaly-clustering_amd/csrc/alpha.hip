@@ -5,10 +5,10 @@
 #include "gemm_hl5.h"
 #include "gemm_hl7.h"
 #ifdef AC_EXPERIMENTAL
-#include "experimental/gemm_hl1.h"
-#include "experimental/gemm_hl3.h"
-#include "experimental/gemm_hl4.h"
-#include "experimental/gemm_hl6.h"
+#include "gemm_hl1.h"
+#include "gemm_hl3.h"
+#include "gemm_hl4.h"
+#include "gemm_hl6.h"
 #endif
 
 // ------------------------------------------------------------------ packing

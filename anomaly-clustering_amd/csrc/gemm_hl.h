@@ -8,7 +8,7 @@
 // fragment interface the epilogues are written against, and the epilogue traits.  The kernels themselves:
 //   gemm_hl2.h   256x128 tile, LDS-DMA ring, staggered schedule, optional two-level accumulation
 //   gemm_hl5.h   256x256 tile, continuous MFMA stream (the ViT linear layers)
-//   experimental/ earlier / negative-result generations, compiled only with -DAC_EXPERIMENTAL
+//   earlier / negative-result generations live outside the package (scratch/gemm_generations/; -DAC_EXPERIMENTAL builds only)
 // The wave's M index lives on the accumulator REGISTERS, its N index on the LANES, so callers put the
 // axis they want to reduce in-lane on A and the axis they want contiguous in memory on B.
 #pragma once
@@ -79,7 +79,7 @@ __device__ inline void raster_rt(int id, int tiles_m, int tiles_n, int group_m, 
 // min_over_row_groups()) so the same epilogue serves both kernels:
 //   FragT<32>: v_mfma_f32_32x32x16_f16, 2x2 tiles, C/D map col = lane&31, row = (i&3)+8(i>>2)+4(lane>>5)
 //   FragT<16>: v_mfma_f32_16x16x32_f16, 4x4 tiles, C/D map col = lane&15, row = 4(lane>>4)+i
-// (the chip sustains a ~14 % higher clock on the 16x16x32 shape: csrc/probe/mfma_rate.hip)
+// (the chip sustains a ~14 % higher clock on the 16x16x32 shape: scratch/probe/mfma_rate.hip)
 template <int SHAPE> struct FragT;
 template <> struct FragT<32> {
   static constexpr int NT = 2, NR = 16, TW = 32;

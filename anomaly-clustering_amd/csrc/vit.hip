@@ -10,9 +10,9 @@
 // conversion pass.
 #include "gemm_hl5.h"
 #ifdef AC_EXPERIMENTAL
-#include "experimental/gemm_hl1.h"
-#include "experimental/gemm_hl3.h"
-#include "experimental/gemm_hl4.h"
+#include "gemm_hl1.h"
+#include "gemm_hl3.h"
+#include "gemm_hl4.h"
 #endif
 
 constexpr int HD = 64;          // head dim (all DINO ViTs)

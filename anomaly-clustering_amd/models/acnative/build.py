@@ -11,6 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "..", "include"))
+GENERATIONS = os.path.normpath(os.path.join(HERE, "..", "..", "..", "scratch", "gemm_generations"))   # not part of the package
 LIB = os.path.join(HERE, "libac_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
@@ -24,7 +25,9 @@ def _sources():
 
 def _deps_mtime():
     m = 0.0
-    for root in (CSRC, os.path.join(CSRC, "experimental"), INCLUDE):
+    for root in (CSRC, GENERATIONS, INCLUDE):
+        if not os.path.isdir(root):
+            continue
         for f in os.listdir(root):
             if f.endswith((".h", ".hip")):
                 m = max(m, os.path.getmtime(os.path.join(root, f)))
@@ -34,10 +37,10 @@ def _deps_mtime():
 def build(force=False, verbose=True, experimental=False):
     """Compile if the library is missing or older than any source/header.  Returns the path.
     experimental=True builds libac_hip_experimental.so with -DAC_EXPERIMENTAL instead: the superseded GEMM
-    generations under csrc/experimental/ become selectable through ac_set_gemm_policy(101..109) for same-box
+    generations under scratch/gemm_generations/ become selectable through ac_set_gemm_policy(101..109) for same-box
     A/B runs (load it with AC_LIB=...).  The product library never contains them."""
     if experimental:
-        return _build(force, verbose, LIB[:-3] + "_experimental.so", OBJ_DIR + "_experimental", ["-DAC_EXPERIMENTAL"])
+        return _build(force, verbose, LIB[:-3] + "_experimental.so", OBJ_DIR + "_experimental", ["-DAC_EXPERIMENTAL", "-I", CSRC, "-I", GENERATIONS])
     return _build(force, verbose, LIB, OBJ_DIR, [])
 
 

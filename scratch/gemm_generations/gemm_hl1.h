@@ -2,7 +2,7 @@
 // v_mfma_f32_32x32x16_f16, two-level accumulation.  Superseded by gemm_hl2.h / gemm_hl5.h; kept for same-box
 // A/B runs in -DAC_EXPERIMENTAL builds only (not part of libac_hip.so).
 #pragma once
-#include "../gemm_hl.h"
+#include "gemm_hl.h"
 
 namespace gemm {
 

@@ -19,7 +19,7 @@
 //   * 2 LDS-DMA instructions per step: steps 7,0,1,2 fetch B(t+2 | t+1), steps 3..6 fetch A(t+2).
 // LDS (160 KB): A in a 3-slot ring (two stages of latency cover), B in a 2-slot ring (one stage).
 #pragma once
-#include "../gemm_hl2.h"
+#include "gemm_hl2.h"
 
 namespace gemm3 {
 

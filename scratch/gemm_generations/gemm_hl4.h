@@ -14,7 +14,7 @@
 //   last use (A row fragments after their row; B fragments in the last row), plus 24 spare registers for
 //   the three fragments that die too late.  One barrier per stage.
 #pragma once
-#include "../gemm_hl2.h"
+#include "gemm_hl2.h"
 
 namespace gemm4 {
 

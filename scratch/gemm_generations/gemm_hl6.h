@@ -22,7 +22,7 @@
 // accumulation (FLUSH), symmetric / swapped epilogues.  All spins are bounded: a protocol error gives
 // wrong numbers, not a hung GPU.
 #pragma once
-#include "../gemm_hl5.h"
+#include "gemm_hl5.h"
 
 namespace gemm6 {
 
