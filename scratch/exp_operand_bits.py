@@ -59,7 +59,7 @@ def main():
             v.zero_()
         return v
 
-    kinds = ["full", "lo-m2", "lo-m4", "lo-m6", "lo-m8", "lo-zero", "zero"]
+    kinds = ["full", "lo-m2", "lo-m4", "lo-m5", "lo-m6", "lo-m8", "lo-zero", "zero"]
     packed = {k: variant(k) for k in kinds}
     mb = torch.empty((n, n * P), dtype=torch.int32, device=dev)
     times = {k: [] for k in kinds}
