@@ -499,12 +499,15 @@ template <> struct gemm::EpiTraits<EpiGeluHl> { static constexpr bool kSymmetric
 // GEMM, no V^T buffer): the V^T fragment of O^T += V^T P^T comes from ds_read_b64_tr_b16, which hands
 // lane i of a 16-lane group column i of a 4-key x 16-feature block, i.e. four consecutive keys of one
 // feature; two of them give the lane its eight keys.
-constexpr int ATT_Q = 128, ATT_KT = 32;
+#ifndef AC_ATT_WAVES
+#define AC_ATT_WAVES 4                     // waves (x 32 queries) per workgroup: 2 / 4 / 8 (same-box A/B builds; 4 ships)
+#endif
+constexpr int ATT_W = AC_ATT_WAVES, ATT_Q = 32 * ATT_W, ATT_KT = 32;
 constexpr int ATT_TILE = 16384;            // K tile [32 keys][256 B] + V tile [32 keys][256 B]
-constexpr int ATT_LDS = 4 * 32 * 65 * 4;   // epilogue transpose buffer, >= the two tile buffers (32 KB)
-static_assert(ATT_LDS >= 2 * ATT_TILE, "tile double buffer must fit");
+constexpr int ATT_LDS = ATT_W * 32 * 65 * 4 > 2 * ATT_TILE ? ATT_W * 32 * 65 * 4 : 2 * ATT_TILE;   // epilogue transpose buffer / the two tile buffers
+static_assert(ATT_W == 2 || ATT_W == 4 || ATT_W == 8, "8 DMA groups per tile are dealt to the waves");
 
-__global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ K,
+__global__ __launch_bounds__(64 * ATT_W, 12 / ATT_W) void attention_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ K,
                                                         const uint8_t* __restrict__ V, uint8_t* __restrict__ O,
                                                         int T, int Tpad, int H, float scale) {
   __shared__ __attribute__((aligned(256))) uint8_t lds[ATT_LDS];
@@ -542,11 +545,12 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
   // DMA map (1 KB per wave-instruction, lane l lands in 16-byte slot l of it; the swizzle goes on the
   // SOURCE address).  K and V tiles: instruction g = key rows 4g..4g+3.
   // Wave w issues g = w and w + 4 of each.
-  const uint8_t* ksrc[2];
-  const uint8_t* vsrc[2];
+  constexpr int ATT_G = 8 / ATT_W;       // DMA groups (of K, and of V) per wave and tile
+  const uint8_t* ksrc[ATT_G];
+  const uint8_t* vsrc[ATT_G];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int g = wave + 4 * j;
+  for (int j = 0; j < ATT_G; ++j) {
+    const int g = wave + ATT_W * j;
     const int krow = 4 * g + (lane >> 4), kslot = (lane & 15) ^ (krow & 15);
     ksrc[j] = Kbase + (size_t)krow * (HD * 4) + kslot * 16;
     const int vslot = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
@@ -559,8 +563,8 @@ __global__ __launch_bounds__(256, 3) void attention_kernel(const uint8_t* __rest
     uint8_t* buf = lds + (kt & 1) * ATT_TILE;
     const bool last = kt == ntiles - 1;               // block-uniform
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int g = wave + 4 * j;
+    for (int j = 0; j < ATT_G; ++j) {
+      const int g = wave + ATT_W * j;
       const uint8_t* vs = vsrc[j] + (size_t)kt * (ATT_KT * HD * 4);
       if (last) {
         const int over = kt * ATT_KT + 4 * g + (lane >> 4) - (T - 1);
@@ -817,7 +821,7 @@ extern "C" int ac_vit_block(const ac_block_weights* w, const float* x_in, float*
   const uint8_t* wqkv = static_cast<const uint8_t*>(w->qkv_w);
   EpiQK eqkv{w->qkv_b, b.q, b.k, b.v, M, C, T, Tp, heads};
   if ((rc = run_gemm(b.h, wqkv, M, 3 * C, C, eqkv, stream))) return rc;
-  hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(256), 0, stream, b.q, b.k, b.v,
+  hipLaunchKernelGGL(attention_kernel, dim3((T + ATT_Q - 1) / ATT_Q, B * heads), dim3(64 * ATT_W), 0, stream, b.q, b.k, b.v,
                      b.o, T, Tp, heads, 1.0f / sqrtf((float)HD));
   EpiResidual ep{w->proj_b, x_in, x_out, M, C};
   if ((rc = run_gemm(b.o, w->proj_w, M, C, C, ep, stream))) return rc;
