@@ -599,7 +599,10 @@ __global__ __launch_bounds__(64 * ATT_W, 12 / ATT_W) void attention_kernel(const
     const uint8_t* Ks = lds + (kt & 1) * ATT_TILE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile kt has landed
     __syncthreads();                                   // ... everybody's has; tile kt-1 is fully consumed
-    if (kt + 1 < ntiles) dma_tile(kt + 1);             // flies under this tile's MFMAs
+#ifndef AC_ATT_ABLATE            // timing-only diagnostic builds (results wrong): 1 no K fragment reads after the first tile,
+#define AC_ATT_ABLATE 0         // 2 no transposed V reads after the first tile, 4 no K / V DMA after the first tile.  0 ships.
+#endif
+    if (kt + 1 < ntiles && !((AC_ATT_ABLATE & 4) && kt > 0)) dma_tile(kt + 1);             // flies under this tile's MFMAs
     // A wave whose 32 queries all lie beyond the sequence (T = 785: the last block of 128 queries holds 17) only helps
     // with the DMA and the barriers: its SIMD slots go to the other workgroups of the CU (3 of the 28 wave slots per
     // head did redundant work on clamped rows: -10 % attention time at T = 785).
@@ -610,8 +613,12 @@ __global__ __launch_bounds__(64 * ATT_W, 12 / ATT_W) void attention_kernel(const
     // V^T fragments: two transposed 4-key blocks per (feature half, key group, plane), issued now so that
     // their latency hides under the S^T MFMAs and the softmax
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    static_assert(AC_ATT_ABLATE == 0 || true, "");
     u32x2_t vr[2][2][2][2];              // [mt][s][plane][j2]
-    {
+    if ((AC_ATT_ABLATE & 2) && kt > 0) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) vr[a >> 3][(a >> 2) & 1][(a >> 1) & 1][a & 1] = u32x2_t{(unsigned)(0x3c003c00u + a + kt), 0x3c003c00u};
+    } else {
       const unsigned vb0 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[0];
       const unsigned vb1 = lds_base + (unsigned)((kt & 1) * ATT_TILE) + vaddr[1];
 #pragma unroll
@@ -632,8 +639,13 @@ __global__ __launch_bounds__(64 * ATT_W, 12 / ATT_W) void attention_kernel(const
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int slot = (s >> 1) * 8 + (s & 1) * 2 + h;
-      half8 kh = *reinterpret_cast<const half8*>(Ks + pr * 256 + ((slot ^ (pr & 15)) << 4));
-      half8 kl = *reinterpret_cast<const half8*>(Ks + pr * 256 + (((slot + 4) ^ (pr & 15)) << 4));
+      half8 kh, kl;
+      if ((AC_ATT_ABLATE & 1) && kt > 0) {
+        kh = qh[s]; kl = ql[s];
+      } else {
+        kh = *reinterpret_cast<const half8*>(Ks + pr * 256 + ((slot ^ (pr & 15)) << 4));
+        kl = *reinterpret_cast<const half8*>(Ks + pr * 256 + (((slot + 4) ^ (pr & 15)) << 4));
+      }
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s_acc, 0, 0, 0);
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s_acc, 0, 0, 0);
       s_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s_acc, 0, 0, 0);
