@@ -478,6 +478,9 @@ def launch_ranks(n, child_cmd, visible_devices=None, poll_s=0.2, timeout_s=480.0
 
 def main():
     args = parse()
+    # dmabuf IPC is the only mode the host driver supports (RCCL / device-tensor sharing between the rank processes):
+    # exported on the GPU boxes already; set here, before anything touches the GPU, for a launcher that did not pass it on
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
