@@ -249,6 +249,7 @@ def main(argv=None):
     print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         global device
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (the host driver's only mode), before the first GPU call
         if args.rehearse_on_one_gpu:
             device = torch.device("cuda:0")
         torch.cuda.set_device(device)
