@@ -44,6 +44,7 @@ import patchcore.datasets.synthetic as synthetic  # noqa: E402
 from patchcore.patchcore import AnomalyClusteringCore  # noqa: E402
 from patchcore.pipeline import HipOps, category_rot, run_categories, run_category, select_bank, shard_bounds  # noqa: E402
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (the host driver's only mode): before the first GPU call
 device = torch.device("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() else "cpu")
 
 _CLASSNAMES = [
@@ -249,7 +250,6 @@ def main(argv=None):
     print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         global device
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (the host driver's only mode), before the first GPU call
         if args.rehearse_on_one_gpu:
             device = torch.device("cuda:0")
         torch.cuda.set_device(device)
