@@ -63,6 +63,7 @@ constexpr int LDS_BYTES = A_SLOTS * A_HALF + B_SLOTS * B_HALF;   // 136 KB
 // blocks all reduce from registers reads them from LDS; they arrive with the tile's first stage), then the next tile id
 constexpr int NORM_BYTES = 2048, LDS_NORMS = 2 * NORM_BYTES;
 constexpr int LDS_EXTRA = LDS_NORMS + 16;
+constexpr int LDS_ABLATE = 4096;              // AC_ABLATE7 & 32 only
 constexpr int FLUSH_STAGES = gemm::FLUSH_STAGES;
 
 // XCD order of a RECTANGLE's tiles (two-way and one-way blocks; gemm_hl.h xcd_lin): windows of 32 tiles dealt to the XCDs in turn
@@ -74,9 +75,14 @@ constexpr int FLUSH_STAGES = gemm::FLUSH_STAGES;
 // travels in bit 16 of the group argument.  (-DAC_G7_WINDOW_RECT=0 / 32 pins one order for A/B builds.)
 constexpr int RECT_WINDOW_TILES_PER_CU = 160;
 // Timing-only diagnostic builds (results are wrong): -DAC_ABLATE7=1 no DMA in the k loop, 2 no fragment reads in the
-// k loop, 4 no MFMAs (combinable).  0 in every shipped build.
+// k loop, 4 no MFMAs; round 6, on the DMA itself: 8 every transfer issued against a descriptor of zero records (nothing
+// fetched; zeros land in LDS), 16 every stage fetches the tile's first k slab (all bytes move, out of the L2), 32 the
+// transfers land in 4 KB of LDS behind the rings (combinable).  0 in every shipped build.
 #ifndef AC_ABLATE7
 #define AC_ABLATE7 0
+#endif
+#ifndef AC_G7_FLAT_DMA
+#define AC_G7_FLAT_DMA 0
 #endif
 
 // -DAC_G7_TIMING (diagnostic builds; read back with ac_debug_wait_times7, alpha.hip): waves 0 and 4 of every persistent
@@ -184,14 +190,20 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   // DMA map (gemm_hl5.h's): a half-tile is 32 (A) / 24 (B) wave-instructions of 1 KB = 8 rows each, issued by waves
   // 0-3 only - the SIMD's arbiter serves its older wave first, so their issue stalls hide behind the partner's MFMAs.
   // Wave w issues rows 32 j + 8 w + (l >> 3); lane l fetches logical chunk (l & 7) ^ ((row >> 1) & 7) of its row.
-  // Registers are what this kernel is short of (240 of 256 hold accumulators and fragments), so the per-lane DMA state
-  // is the lane number alone: row and chunk are rebuilt at every burst, and the lane number is redefined by an empty
-  // asm there - hipcc would otherwise hoist the 14 row offsets of a stage out of the k loop (28 registers, spilled).
+  // Round 6: the transfers are BUFFER loads (buffer_load_dwordx4 ... offen lds).  One descriptor per operand and tile
+  // (base = the tile's first row, num_records = the bytes of its rows inside the problem: the range check drops the
+  // rows behind the edge - they used to be clamped to the last row, and the epilogue never looks at them either way),
+  // ONE per-lane byte offset for the whole launch (row 8 w + (l >> 3) of a burst, swizzled chunk: the same for both
+  // operands, since both have K * 4 bytes per row), the burst (32 j rows) and the stage (128 t bytes) in the scalar
+  // offset: no vector instruction per transfer.  (Rounds 1-5: global_load_lds with a 64-bit address per lane and
+  // transfer, rebuilt at every burst because hoisted it costs 28 registers - 76 VALU per 64 MFMAs in the loader waves'
+  // stage block, v_mad_u64_u32 among them.  -DAC_G7_FLAT_DMA=1 builds that form for A/B.)
   constexpr int LW = 4;                          // DMA-issuing waves (all eight: +7 %, round-5 A/B)
   const bool loader = wave < LW;
   if (loader) __builtin_amdgcn_s_setprio(2);
   const unsigned ld32 = (unsigned)K * 4u;
   int m0 = 0, n0 = 0;
+#if AC_G7_FLAT_DMA
   auto dma = [&](const uint8_t* src, int first, int last, int t, uint8_t* dst, int pieces) {
     int l = lane;
     asm volatile("" : "+v"(l));
@@ -206,6 +218,46 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   };
   auto dmaA = [&](int t, int slot) { if (loader) dma(A, m0, M - 1, t, Aring + slot * A_HALF, BM / (8 * LW)); };
   auto dmaB = [&](int t, int slot) { if (loader) dma(B, n0, N - 1, t, Bring + slot * B_HALF, BN / (8 * LW)); };
+  auto set_tile = [&]() {};
+#else
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  const int dma_r = (wave & (LW - 1)) * 8 + (lane >> 3);
+  const int dma_voff = dma_r * (int)ld32 + ((lane & 7) ^ ((dma_r >> 1) & 7)) * 16;     // < 32 rows: K < 2^14 keeps it in 31 bits
+  // The descriptor of an operand and tile as three scalars (base, bytes); dma() builds the 128-bit value from them
+  // behind readfirstlane, so that hipcc can PROVE it wave-uniform - carried round the tile loop as a descriptor it
+  // lands in vector registers and every transfer is wrapped in a waterfall loop (v_readfirstlane x 4, compare, saveexec).
+  struct TileBuf { unsigned lo, hi, bytes; };
+  TileBuf tbA = {0, 0, 0}, tbB = {0, 0, 0};
+  auto tile_buf = [&](const uint8_t* src, int first, int rows_total, int rows_tile) {
+    const int rows = max(0, min(rows_total - first, rows_tile));
+    const uint64_t base = reinterpret_cast<uint64_t>(src) + (uint64_t)(unsigned)first * ld32;
+    TileBuf b = {(unsigned)base, (unsigned)(base >> 32), (unsigned)rows * ld32};
+    if (AC_ABLATE7 & 8) b.bytes = 0;             // timing only: every transfer issued, none fetched
+    return b;
+  };
+  auto set_tile = [&]() {                        // after m0 / n0 changed, before the next tile's first transfer
+    tbA = tile_buf(A, m0, M, BM);
+    tbB = tile_buf(B, n0, N, BN);
+  };
+  auto dma = [&](const TileBuf& tb, int t, uint8_t* dst, int pieces) {
+    if (AC_ABLATE7 & 16) t = 0;                  // timing only: every stage fetches the tile's first k slab (L2 hits)
+    const uint64_t base = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)tb.lo) |
+                          (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)tb.hi) << 32;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0,
+                                                        __builtin_amdgcn_readfirstlane((int)tb.bytes), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= pieces) break;
+      // (AC_ABLATE7 & 32, timing only: every transfer lands in 4 KB behind everything else - the rings keep the data of
+      // the launch's first prologue, so the MFMAs go on multiplying real numbers)
+      uint8_t* const d = (AC_ABLATE7 & 32) ? smem + LDS_BYTES + LDS_EXTRA + (wave & (LW - 1)) * 1024
+                                           : dst + (j * LW + (wave & (LW - 1))) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)d, 16, dma_voff, (int)(8u * LW * j * ld32) + t * 128, 0, 0);
+    }
+  };
+  auto dmaA = [&](int t, int slot) { if (loader) dma(tbA, t, Aring + slot * A_HALF, BM / (8 * LW)); };
+  auto dmaB = [&](int t, int slot) { if (loader) dma(tbB, t, Bring + slot * B_HALF, BN / (8 * LW)); };
+#endif
   auto barrier = [&]() { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
 
   // fragment offsets: 16-row tile t of this wave's rows / columns is base + t * 2048 bytes (the XOR swizzle term
@@ -229,7 +281,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   if (queue) {
     if (tid == 0) resolve(take());
     __syncthreads();
-    id = *lds_next;
+    id = __builtin_amdgcn_readfirstlane(*lds_next);   // block-uniform, and known to be: the tile arithmetic stays scalar
     __syncthreads();                               // everyone has read it before thread 0 may overwrite it
     if (id < 0) return;
   } else {
@@ -255,6 +307,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   auto issue_prologue = [&]() {
     fast_next = epi.tile_is_fast(m0, n0, BM, BN, NTN * 16);
     norm_par ^= 1;
+    set_tile();
     if (fast_next && wave < 2) {
       const float* src = wave == 0 ? epi.key_sq + m0 : epi.qry_sq + n0;
       const int l4 = wave == 0 || lane < BN / 4 ? lane * 4 : 0;           // column norms: 48 lanes carry data
@@ -475,6 +528,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
                   int group_m = 6, int part = 0, int nparts = 1, bool dynamic = true) {
   if (M <= 0 || N <= 0) return AC_OK;
   if (K % BK != 0 || K <= 0) return ac_fail(AC_EINVAL, "gemm_hl7: K=%d must be a positive multiple of 32", K);
+  if (K > (1 << 20)) return ac_fail(AC_EINVAL, "gemm_hl7: K=%d too large (a tile's rows must fit a 31-bit buffer offset)", K);
   if (nparts < 1 || part < 0 || part >= nparts) return ac_fail(AC_EINVAL, "gemm_hl7: bad part %d/%d", part, nparts);
   if (group_m < 1 || group_m > 0xffff) return ac_fail(AC_EINVAL, "gemm_hl7: group_m=%d out of range", group_m);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -485,7 +539,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
     total = tri_rows_before(tiles_m, tiles_n);
   }
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
-  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi>), LDS_BYTES + LDS_EXTRA, &attr_done)) return rc;
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi>), LDS_BYTES + LDS_EXTRA + ((AC_ABLATE7 & 32) ? LDS_ABLATE : 0), &attr_done)) return rc;
   const long long lo = (total * part / nparts) & ~7LL;
   const long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
@@ -499,9 +553,11 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
 #ifdef AC_G7_WINDOW_RECT
   const bool windowed = AC_G7_WINDOW_RECT != 0;
 #else
-  const bool windowed = hi - lo < (long long)RECT_WINDOW_TILES_PER_CU * n_cu;
+  // from the WHOLE id space, not from this part's slice: the two orders are different bijections of the same ids, so every
+  // part of a sliced launch must pick the same one (or some tiles run twice and others never)
+  const bool windowed = total < (long long)RECT_WINDOW_TILES_PER_CU * n_cu;
 #endif
-  hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA, stream,
+  hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA + ((AC_ABLATE7 & 32) ? LDS_ABLATE : 0), stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
                      group_m | (windowed ? 1 << 16 : 0), (int)lo, (int)hi, (int)total, epi, queue);
   return ac_check_launch("gemm_hl7");

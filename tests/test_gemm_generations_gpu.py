@@ -63,7 +63,7 @@ def test_all_pairs_tiles_agree_bitwise(dev):
       * symmetric on shapes whose blocks straddle the diagonal and the image boundaries in every way (P = 100, 67, 130; K
         of 1, 2, 3, 8 stages: below one flush interval, and past it with P = 784 / D = 640: 20 stages),
       * two-way and one-way rectangles with ragged edges, one-image blocks included, and one rectangle large enough for
-        the second XCD order of the new kernel."""
+        the second XCD order of the new kernel - whole, and the one-way form in two slices."""
     import acnative
     from _synth import clustered_embeddings
 
@@ -109,6 +109,10 @@ def test_all_pairs_tiles_agree_bitwise(dev):
     assert torch.equal(a1, b1) and torch.equal(a2, b2)
     a, b = both(lambda: acnative.pair_block(B, A))
     assert torch.equal(a, b) and torch.isfinite(a.view(torch.float32)).all()
+    # ... and SLICED in two: each slice (25 676 tiles) is below the switch-over of the XCD order, the whole launch
+    # above it - every part must walk the id space in the order the WHOLE launch picks, or tiles are lost between the parts
+    parts = [acnative.pair_block(B, A, part=r, nparts=2) for r in range(2)]
+    assert torch.equal(torch.stack([x.view(torch.float32) for x in parts]).min(0)[0], b.view(torch.float32))
 
 
 def test_unknown_policy_is_rejected():
