@@ -369,8 +369,11 @@ static int launch_pair_min(const void* A, const void* B, int M, int N, int K, co
 #ifndef AC_PAIR_TILE
 #define AC_PAIR_TILE 192
 #endif
+#ifndef AC_G7_MT
+#define AC_G7_MT 4                  // 8: the four-wave, 512-register form of the 256x192 kernel (A/B builds; gemm_hl7.h)
+#endif
   if (AC_PAIR_TILE == 192 && ac_gemm_policy() != AC_GEMM_256x128)
-    return gemm7::launch<EpiPairMin>(A, B, M, N, K, epi, stream, group_m, part, nparts, AC_PAIR_DYNAMIC != 0);
+    return gemm7::launch<EpiPairMin, AC_G7_MT>(A, B, M, N, K, epi, stream, group_m, part, nparts, AC_PAIR_DYNAMIC != 0);
   return gemm2::launch<EpiPairMin, true>(A, B, M, N, K, epi, stream, group_m, part, nparts, false, AC_PAIR_DYNAMIC != 0);
 }
 

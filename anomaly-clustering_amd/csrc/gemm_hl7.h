@@ -54,7 +54,11 @@ using gemm2::lptr_t;
 using gemm2::tile_off;
 using Frag = gemm::FragT<16>;
 
-constexpr int BM = 256, BN = 192, BK = 32, THREADS = 512;
+constexpr int BM = 256, BN = 192, BK = 32;
+// MT = 16-row MFMA tiles per wave: 4 -> eight waves of 64 x 96 (two per SIMD, 256 registers each: the product);
+// 8 -> FOUR waves of 128 x 96, one per SIMD with the whole 512-register file (round 6, VERDICT r05 item 2: -32 % fragment
+// bytes per MFMA; -DAC_G7_MT=8 builds it).
+constexpr int threads_of(int MT) { return 2048 / MT; }
 constexpr int NTN = 6;                                   // 16-column MFMA tiles per wave (4 row tiles always)
 constexpr int A_HALF = BM * 128, B_HALF = BN * 128;      // 32 KB, 24 KB per stage
 constexpr int A_SLOTS = 2, B_SLOTS = 3;
@@ -83,6 +87,12 @@ constexpr int RECT_WINDOW_TILES_PER_CU = 160;
 #endif
 #ifndef AC_G7_FLAT_DMA
 #define AC_G7_FLAT_DMA 0
+#endif
+#ifndef AC_G7_PIN_AGPR
+#define AC_G7_PIN_AGPR 0
+#endif
+#ifndef AC_G7_KATTR
+#define AC_G7_KATTR
 #endif
 
 // -DAC_G7_TIMING (diagnostic builds; read back with ac_debug_wait_times7, alpha.hip): waves 0 and 4 of every persistent
@@ -172,8 +182,8 @@ __device__ inline void tile_of(int id, int total, int tiles_m, int tiles_n, int 
   gemm::raster_rt(id, tiles_m, tiles_n, group_m & 0xffff, (group_m >> 16) & 1, tm, tn);
 }
 
-template <class Epi>
-__global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+template <class Epi, int MT = 4>
+__global__ __launch_bounds__(threads_of(MT), MT == 4 ? 2 : 1) AC_G7_KATTR void kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                      int M, int N, int K, int tiles_m, int tiles_n, int group_m,
                                                      int id_lo, int id_hi, int total, Epi epi, unsigned* queue) {
   static_assert(LDS_BYTES + LDS_EXTRA <= 160 * 1024, "LDS");
@@ -184,7 +194,8 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   int* const lds_next = reinterpret_cast<int*>(smem + LDS_BYTES + LDS_NORMS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;       // MT = 4: 4 x 2 waves, MT = 8: 2 x 2
+  constexpr int WROWS = 16 * MT;                 // rows of a wave's block
   const int nk = K / BK;
 
   // DMA map (gemm_hl5.h's): a half-tile is 32 (A) / 24 (B) wave-instructions of 1 KB = 8 rows each, issued by waves
@@ -199,8 +210,8 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   // transfer, rebuilt at every burst because hoisted it costs 28 registers - 76 VALU per 64 MFMAs in the loader waves'
   // stage block, v_mad_u64_u32 among them.  -DAC_G7_FLAT_DMA=1 builds that form for A/B.)
   constexpr int LW = 4;                          // DMA-issuing waves (all eight: +7 %, round-5 A/B)
-  const bool loader = wave < LW;
-  if (loader) __builtin_amdgcn_s_setprio(2);
+  const bool loader = MT == 8 || wave < LW;      // (four waves: every one of them)
+  if (MT == 4 && loader) __builtin_amdgcn_s_setprio(2);
   const unsigned ld32 = (unsigned)K * 4u;
   int m0 = 0, n0 = 0;
 #if AC_G7_FLAT_DMA
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
   // fragment offsets: 16-row tile t of this wave's rows / columns is base + t * 2048 bytes (the XOR swizzle term
   // (row >> 1) & 7 is unchanged by +16 rows; 96 wn is a multiple of 16 too); the lo plane of a row is its hi plane's
   // chunk + 4, i.e. the same offset with bit 6 flipped (slot bases are multiples of 128)
-  const int a_hi = tile_off(wm * 64 + (lane & 15), (lane >> 4));
+  const int a_hi = tile_off(wm * WROWS + (lane & 15), (lane >> 4));
   const int b_hi = tile_off(wn * (NTN * 16) + (lane & 15), (lane >> 4));
   auto frag = [&](int slot_off, int off_hi, int t, half8& hi, half8& lo) {      // slot_off: byte offset of the ring slot in smem
     const int oh = slot_off + off_hi, ol = oh ^ 64;      // t * 2048 stays an immediate offset of the ds_read
@@ -329,9 +340,9 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     const int m0c = m0, n0c = n0;                                 // this tile (m0, n0 move on to the next one before its epilogue)
     const bool fast_cur = fast_next;                              // ... is fast, its norms are in LDS buffer norm_cur
     const int norm_cur = norm_par;
-    f32x4 acc[4][NTN], tot[4][NTN];
+    f32x4 acc[MT][NTN], tot[MT][NTN];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NTN; ++ni)
 #pragma unroll
@@ -344,9 +355,9 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     barrier();
-    half8 ah[4], al[4], bh, bl;
+    half8 ah[MT], al[MT], bh, bl;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) frag(0, a_hi, t, ah[t], al[t]);
+    for (int t = 0; t < MT; ++t) frag(0, a_hi, t, ah[t], al[t]);
     frag(B0, b_hi, 0, bh, bl);
 #ifdef AC_G7_TIMING
     const unsigned long long tt_b = __builtin_readcyclecounter();
@@ -358,6 +369,12 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       constexpr bool STEADY = decltype(steady)::value;   // branch-free body while three more stages follow
       const bool more1 = STEADY || kt + 1 < nk, more2 = STEADY || kt + 2 < nk, more3 = STEADY || kt + 3 < nk;
       const int sb1 = sb == B_SLOTS - 1 ? 0 : sb + 1;    // (kt + 1) % B_SLOTS
+#if AC_G7_PIN_AGPR                                   // (MT = 8 experiments: say where the MFMA accumulators live)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTN; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
+#endif
       const int Bs = B0 + sb * B_HALF, Bn = B0 + sb1 * B_HALF, An = ((kt + 1) & 1) * A_HALF;
       // One column step = three passes over the four row tiles (per element the passes stay in the order hi*lo, lo*hi,
       // hi*hi).  The lo half of the B fragment is dead after the first pass: the next step's fragment is read right
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
         const bool last = ni == NTN - 1;
         if (!(AC_ABLATE7 & 4)) {
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+          for (int mi = 0; mi < MT; ++mi)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -397,13 +414,13 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
           if (!(AC_ABLATE7 & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
           if (last && more1 && !(AC_ABLATE7 & 2))
             al[mi] = *reinterpret_cast<const half8*>(smem + ((An + a_hi) ^ 64) + mi * 2048);
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
           if (!(AC_ABLATE7 & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
           if (last && more1 && !(AC_ABLATE7 & 2)) ah[mi] = *reinterpret_cast<const half8*>(smem + (An + a_hi) + mi * 2048);
         }
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
       // Two-level accumulation (gemm_hl.h): flush the MFMA accumulator every 512 k-terms.
       if ((kt & (FLUSH_STAGES - 1)) == FLUSH_STAGES - 1) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NTN; ++ni)
 #pragma unroll
@@ -443,12 +460,12 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     ++tt_tiles;
 #endif
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NTN; ++ni)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[mi][ni][i] += tot[mi][ni][i];
-    const int m_wave = m0c + wm * 64, n_wave = n0c + wn * (NTN * 16);
+    const int n_wave = n0c + wn * (NTN * 16);
     int next = -1;
     if (queue) {
       next = __builtin_amdgcn_readfirstlane(*lds_next);        // block-uniform: the tile arithmetic stays scalar
@@ -466,48 +483,55 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
     const unsigned long long tt_e = __builtin_readcyclecounter();
     tt_e2 += tt_e - tt_d;
 #endif
-    // ---- epilogue: the wave's 64 x 96 block at rows m_wave, columns n_wave
+    // ---- epilogue: the wave's block as MT / 4 pieces of 64 x 96, at rows m_wave, columns n_wave
     const bool sym = epi.symmetric;
-    // symmetric problem: only elements with row <= column are used, each reduced in both directions (gemm_hl2.h).
-    // A block wholly above the diagonal and inside the problem: both reductions from registers (epi.fast_wide);
-    // otherwise the general code on a 64 x 64 and a 64 x 32 piece, per-element diagonal mask where a piece crosses it.
-    const bool below = sym && m_wave > n_wave + (NTN * 16 - 1);
-    if (fast_cur) {
-      const float* nb = reinterpret_cast<const float*>(smem + LDS_BYTES + norm_cur * NORM_BYTES);
-      f32x4 ks[4];
-      float qs[NTN];
+    auto epilogue_half = [&](auto hm_c) {
+      constexpr int hm = decltype(hm_c)::value;
+      f32x4 (&acch)[4][NTN] = *reinterpret_cast<f32x4 (*)[4][NTN]>(&acc[4 * hm]);
+      const int m_wave = m0c + wm * WROWS + 64 * hm;
+      // symmetric problem: only elements with row <= column are used, each reduced in both directions (gemm_hl2.h).
+      // A block wholly above the diagonal and inside the problem: both reductions from registers (epi.fast_wide);
+      // otherwise the general code on a 64 x 64 and a 64 x 32 piece, per-element diagonal mask where a piece crosses it.
+      const bool below = sym && m_wave > n_wave + (NTN * 16 - 1);
+      if (fast_cur) {
+        const float* nb = reinterpret_cast<const float*>(smem + LDS_BYTES + norm_cur * NORM_BYTES);
+        f32x4 ks[4];
+        float qs[NTN];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(nb + wm * 64 + 16 * mi + 4 * (lane >> 4));
+        for (int mi = 0; mi < 4; ++mi) ks[mi] = *reinterpret_cast<const f32x4*>(nb + wm * WROWS + 64 * hm + 16 * mi + 4 * (lane >> 4));
 #pragma unroll
-      for (int ni = 0; ni < NTN; ++ni) qs[ni] = nb[256 + wn * (NTN * 16) + 16 * ni + (lane & 15)];
-      epi.template fast_reduce<NTN>(acc, ks, qs, m_wave, n_wave, lane, sym || epi.two_way);
-    } else if (!below) {
-      const bool both = sym || epi.two_way;
-      const bool clear = !sym || m_wave + 63 <= n_wave;
-      if (!(clear && epi.template fast_wide<NTN>(acc, m_wave, n_wave, lane, both))) {
-        float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+        for (int ni = 0; ni < NTN; ++ni) qs[ni] = nb[256 + wn * (NTN * 16) + 16 * ni + (lane & 15)];
+        epi.template fast_reduce<NTN>(acch, ks, qs, m_wave, n_wave, lane, sym || epi.two_way);
+      } else if (!below) {
+        const bool both = sym || epi.two_way;
+        const bool clear = !sym || m_wave + 63 <= n_wave;
+        if (!(clear && epi.template fast_wide<NTN>(acch, m_wave, n_wave, lane, both))) {
+          float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 65);
 #pragma unroll
-        for (int h = 0; h < (NTN + 3) / 4; ++h) {
-          Frag f;
+          for (int h = 0; h < (NTN + 3) / 4; ++h) {
+            Frag f;
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+              for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) f.acc[mi][ni][i] = (4 * h + ni < NTN) ? acc[mi][(4 * h + ni) % NTN][i] : 0.f;
-          const int n_sub = n_wave + 64 * h, n_lim = n_wave + NTN * 16, width = min(64, NTN * 16 - 64 * h);
-          if (sym && m_wave > n_sub + width - 1) continue;          // this piece lies below the diagonal
-          const bool cross = sym && m_wave + 63 > n_sub;           // some of its elements do
-          epi(f, m_wave, n_sub, lane, cross, n_lim);
-          if (both) epi.transposed(f, m_wave, n_sub, lane, scratch, cross, n_lim);
+                for (int i = 0; i < 4; ++i) f.acc[mi][ni][i] = (4 * h + ni < NTN) ? acch[mi][(4 * h + ni) % NTN][i] : 0.f;
+            const int n_sub = n_wave + 64 * h, n_lim = n_wave + NTN * 16, width = min(64, NTN * 16 - 64 * h);
+            if (sym && m_wave > n_sub + width - 1) continue;          // this piece lies below the diagonal
+            const bool cross = sym && m_wave + 63 > n_sub;           // some of its elements do
+            epi(f, m_wave, n_sub, lane, cross, n_lim);
+            if (both) epi.transposed(f, m_wave, n_sub, lane, scratch, cross, n_lim);
+          }
         }
       }
-    }
+    };
+    epilogue_half(std::integral_constant<int, 0>{});
+    if constexpr (MT == 8) epilogue_half(std::integral_constant<int, 1>{});
 
 #ifdef AC_G7_TIMING
     tt_epi += __builtin_readcyclecounter() - tt_c;
-    if (next < 0 && (tid == 0 || tid == 256) && blockIdx.x < 1024) {
-      unsigned long long* o = ac_wait_times7 + (blockIdx.x * 2 + (tid >> 8)) * 8;
+    if (next < 0 && (tid == 0 || tid == threads_of(MT) / 2) && blockIdx.x < 1024) {
+      unsigned long long* o = ac_wait_times7 + (blockIdx.x * 2 + (tid != 0)) * 8;
       o[0] = tt_tiles; o[1] = tt_pro; o[2] = tt_loop; o[3] = tt_vm; o[4] = tt_bar - tt_vm; o[5] = tt_epi;
       o[6] = __builtin_readcyclecounter() - tt_start; o[7] = nk | (tt_e1 / (tt_tiles ? tt_tiles : 1)) << 16 | (tt_e2 / (tt_tiles ? tt_tiles : 1)) << 40;
     }
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(THREADS, 2) void kernel(const uint8_t* __restrict__
 }
 
 // Host launcher: gemm_hl2.h's contract (M, N arbitrary, K % 32 == 0; part / nparts slices of the tile-id space).
-template <class Epi>
+template <class Epi, int MT = 4>
 inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& epi, hipStream_t stream,
                   int group_m = 6, int part = 0, int nparts = 1, bool dynamic = true) {
   if (M <= 0 || N <= 0) return AC_OK;
@@ -539,7 +563,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
     total = tri_rows_before(tiles_m, tiles_n);
   }
   static unsigned long long attr_done = 0;       // per instantiation, one bit per device
-  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi>), LDS_BYTES + LDS_EXTRA + ((AC_ABLATE7 & 32) ? LDS_ABLATE : 0), &attr_done)) return rc;
+  if (int rc = ac_set_max_lds(reinterpret_cast<const void*>(&kernel<Epi, MT>), LDS_BYTES + LDS_EXTRA + ((AC_ABLATE7 & 32) ? LDS_ABLATE : 0), &attr_done)) return rc;
   const long long lo = (total * part / nparts) & ~7LL;
   const long long hi = (part == nparts - 1) ? total : ((total * (part + 1) / nparts) & ~7LL);
   if (hi <= lo) return AC_OK;
@@ -557,7 +581,7 @@ inline int launch(const void* A, const void* B, int M, int N, int K, const Epi& 
   // part of a sliced launch must pick the same one (or some tiles run twice and others never)
   const bool windowed = total < (long long)RECT_WINDOW_TILES_PER_CU * n_cu;
 #endif
-  hipLaunchKernelGGL((kernel<Epi>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES + LDS_EXTRA + ((AC_ABLATE7 & 32) ? LDS_ABLATE : 0), stream,
+  hipLaunchKernelGGL((kernel<Epi, MT>), dim3((unsigned)grid), dim3(threads_of(MT)), LDS_BYTES + LDS_EXTRA + ((AC_ABLATE7 & 32) ? LDS_ABLATE : 0), stream,
                      static_cast<const uint8_t*>(A), static_cast<const uint8_t*>(B), M, N, K, tiles_m, tiles_n,
                      group_m | (windowed ? 1 << 16 : 0), (int)lo, (int)hi, (int)total, epi, queue);
   return ac_check_launch("gemm_hl7");
