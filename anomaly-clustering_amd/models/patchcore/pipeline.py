@@ -105,18 +105,44 @@ def unsup_schedule(bounds, rank, c):
         slo, shi = bounds[src]
         mine, theirs = (lo, hi), (slo, shi)
         if 2 * k == world:
-            # the pair {rank, src} meets from both sides at this step: the lower rank takes the first half of
-            # ITS images against all of the higher rank's, the higher rank the remaining images of the lower
+            # the pair {rank, src} meets from both sides at this step: the lower rank takes ALL of its images against
+            # the first half of the HIGHER rank's, the higher rank its remaining images against all of the lower's.
+            # (Round 6: the higher shard is the one that is split - rounds 2-5 split the lower - so that the lower
+            # rank's block keeps its whole shard as one operand and joins the rectangle of its other steps:
+            # merge_later_steps.)
             low, high = min(rank, src), max(rank, src)
-            llo, lhi = bounds[low]
-            mid = llo + (lhi - llo + 1) // 2
+            hlo, hhi = bounds[high]
+            mid = hlo + (hhi - hlo + 1) // 2
             if rank == low:
-                mine = (llo, mid)
+                theirs = (hlo, mid)
             else:
-                theirs = (mid, lhi)
+                mine = (mid, hhi)
         for a in _subranges(mine[0], mine[1], c):
             for b in _subranges(theirs[0], theirs[1], c):
                 yield ("two", k, a, b)
+
+
+def merge_later_steps(items, c, P, budget=MINBUF_BYTES):
+    """Fuse the two-way blocks of ring steps >= 1 (unsup_schedule's items, in step order) into as few launches as their
+    shapes allow: a run of consecutive steps whose local block is the same, whose remote blocks follow one another in
+    image order and lie on the same side of the local block (the orientation rule of _UnsupJob.run: the block with the
+    lower image indices is the row operand) is ONE rectangle.  -> [("two", (k_first, k_last), a, b)].
+    A rank of an 8-GPU run of an 83-image category then runs its steps 1-4 as one launch of 11 x 39 images instead of
+    three of 11 x 11 and one of 6 x 11, each with its own ramp and tail; the ranks of the upper
+    half, whose ring wraps round image 0, as two or three.  The fused block respects the launch limits (c images a
+    side would have been split by unsup_schedule anyway; the matrices of minima stay inside the budget)."""
+    out = []
+    for it in items:
+        _, k, a, b = it
+        if out:
+            _, (k1, k2), pa, pb = out[-1]
+            fused = (pb[0], b[1])
+            if (k == k2 + 1 and pa == a and pb[1] == b[0] and (pb[0] > a[0]) == (b[0] > a[0]) and fused[1] - fused[0] <= c
+                    and (a[1] - a[0]) * (fused[1] - fused[0]) * P * 4 <= budget):
+                out[-1] = ("two", (k1, k), a, fused)
+                continue
+        out.append(("two", (k, k), a, b))
+    return out
 
 
 # ------------------------------------------------------------------ ViT launch sizes by whole rounds of the chip
@@ -485,6 +511,10 @@ class _Ring:
         self.depth = max(2, min(max(last_step, 1), remote_bytes // per_buffer))
         self.bufs = [None] * self.depth
         self.pending = {}
+        # every step posted up front: ONE receive store, the shards side by side in STEP order, so that a run of steps is
+        # one block (get_run)
+        self.contig = False
+        self.store, self.off = None, {}
         self.stage = world > 1 and dist.get_backend(group) != "nccl" and local.tensors()[0].is_cuda
         self._host_local = None
         # depth is a function of the category's SHAPE and the caller's budget only, so every rank arrives at the same
@@ -510,10 +540,22 @@ class _Ring:
             slots = [k % self.depth for k in steps]
             if len(set(slots)) != len(slots):
                 raise RuntimeError("ring: batched steps %r share receive buffers %r" % (steps, slots))
+            self._lay_out(steps)
             self._post(steps)
         else:
             for k in range(1, min(self.depth, last_step) + 1):
                 self.prefetch(k)
+
+    def _lay_out(self, steps):
+        """One receive store for all of `steps`: the shard of step k at image offset off[k], no gaps."""
+        total = 0
+        for k in steps:
+            self.off[k] = total
+            total += self.sizes[(self.rank + k) % self.world]
+        self.contig = True
+        if total:
+            self.store = (self.local.empty_like(total) if hasattr(self.local, "empty_like")
+                          else self.ops.empty_packed(total, self.local))
 
     def _peer(self, v):
         r = (v - self.rot) % self.world
@@ -531,10 +573,13 @@ class _Ring:
             src, dst = (self.rank + k) % self.world, (self.rank - k) % self.world
             n_src = self.sizes[src]
             slot = k % self.depth
-            if self.bufs[slot] is None and n_src:
-                self.bufs[slot] = (self.local.empty_like(self.cap) if hasattr(self.local, "empty_like")
-                                   else self.ops.empty_packed(self.cap, self.local))
-            recv = self.bufs[slot].slice(0, n_src) if n_src else None
+            if self.contig:
+                recv = self.store.slice(self.off[k], self.off[k] + n_src) if n_src else None
+            else:
+                if self.bufs[slot] is None and n_src:
+                    self.bufs[slot] = (self.local.empty_like(self.cap) if hasattr(self.local, "empty_like")
+                                       else self.ops.empty_packed(self.cap, self.local))
+                recv = self.bufs[slot].slice(0, n_src) if n_src else None
             send_t = self.local.tensors() if self.local.n else []          # an empty shard is neither sent nor received
             recv_t = recv.tensors() if n_src else []
             host_recv = None
@@ -567,6 +612,29 @@ class _Ring:
             recv = self.decode(recv)          # new tensors: the receive buffer itself is free again once this is queued
         self.prefetch(k - 1 + self.depth)
         return recv
+
+    def get_run(self, k1, k2):
+        """The shards of steps k1 .. k2 as ONE block, in step order (None when all of them are empty); decoded by one
+        call.  Only when every step was posted up front into the one store (self.contig)."""
+        if k1 == k2:
+            return self.get(k1)
+        if not self.contig:
+            raise RuntimeError("ring: get_run needs every step posted into one store")
+        n = 0
+        for k in range(k1, k2 + 1):
+            batch, recv, host_recv = self.pending.pop(k)
+            if not batch["waited"]:
+                for w in batch["works"]:
+                    w.wait()
+                batch["waited"] = True
+            if host_recv is not None:
+                for d, h in zip(recv.tensors() if recv is not None else [], host_recv):
+                    d.copy_(h)
+            n += recv.n if recv is not None else 0
+        if n == 0:
+            return None
+        blk = self.store.slice(self.off[k1], self.off[k1] + n)
+        return self.decode(blk) if self.decode is not None else blk
 
 
 def _slice_global(pk, base, rng):
@@ -638,6 +706,41 @@ class _UnsupJob:
                 ops.pair_accumulate(mb, P, MEAN, NO_SELF, shift, acc[b[0] * P: b[1] * P])     # keys A, queries B
                 ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[a[0] * P: a[1] * P])    # keys B, queries A
 
+    def run_later(self):
+        """Every step >= 1.  With all of the ring's shards in one store (a small category: everything was posted up front)
+        the steps' blocks run as the few rectangles merge_later_steps makes of them; otherwise step by step.
+        AC_RING_MERGE=0 keeps the step-by-step order selectable (A/B on the first multi-GPU node)."""
+        last = self.last_step
+        if last < 1:
+            return
+        if not (getattr(self.ring, "contig", False) and last > 1 and os.environ.get("AC_RING_MERGE", "1") != "0"):
+            for step in range(1, last + 1):
+                self.run(step)
+            return
+        items = [it for step in range(1, last + 1) for it in self.by_step.get(step, [])]
+        covered = set()
+        for _, (k1, k2), a, b in merge_later_steps(items, block_images(self.P, self.budget), self.P, self.budget):
+            if (k1, k2) in covered:          # (several sub-blocks of one step: the shard is fetched once)
+                remote = self._last_remote
+            else:
+                remote = self._last_remote = self.ring.get_run(k1, k2)
+                covered.add((k1, k2))
+            self._two_way(a, b, remote, self.bounds[(self.rank + k1) % self.world][0])
+        self._last_remote = None
+        for k in range(1, last + 1):          # every rank takes part in every exchange, work or not
+            if k in self.ring.pending:
+                self.ring.get(k)
+
+    def _two_way(self, a, b, remote, rbase):
+        ops, P, acc, shift, lo = self.ops, self.P, self.acc, self.shift, self.lo
+        A = _slice_global(self.pk, lo, a)
+        B = _slice_global(remote, rbase, b)
+        if a[0] > b[0]:                       # canonical orientation (see run)
+            a, b, A, B = b, a, B, A
+        mb, mbt = ops.pair_block(A, B, two_way=True)
+        ops.pair_accumulate(mb, P, MEAN, NO_SELF, shift, acc[b[0] * P: b[1] * P])
+        ops.pair_accumulate(mbt, P, MEAN, NO_SELF, shift, acc[a[0] * P: a[1] * P])
+
     def finish(self):
         P = self.P
         self.ring = None
@@ -672,8 +775,8 @@ def alpha_weights_unsupervised(ops, pk_loc, bounds, rank, world, group, device, 
         dist.all_reduce(job.m, op=dist.ReduceOp.MAX, group=group)
     job.prepare()
     job.post()
-    for step in range(0, job.last_step + 1):
-        job.run(step)
+    job.run(0)
+    job.run_later()
     if world > 1:
         dist.all_reduce(job.acc, op=dist.ReduceOp.SUM, group=group)
     return job.finish()
@@ -722,6 +825,22 @@ class _SupJob:
             return
         self.ops.nn_scan(self.state, keys, self.ops.h16(keys), self.pk, self.q16, self.slack)
 
+    def run_later(self):
+        """Every step >= 1: the bank shards of the other ranks.  With all of them in one store (every step posted up
+        front) they are ONE block of keys and one scan - the search is exact and takes the min over all bank patches,
+        so neither the order of the shards nor their grouping changes a bit of the result.  AC_RING_MERGE=0: shard by
+        shard."""
+        last = self.last_step
+        if last < 1:
+            return
+        if getattr(self.ring, "contig", False) and last > 1 and os.environ.get("AC_RING_MERGE", "1") != "0":
+            keys = self.ring.get_run(1, last)
+            if keys is not None and keys.n and self.n_loc:
+                self.ops.nn_scan(self.state, keys, self.ops.h16(keys), self.pk, self.q16, self.slack)
+            return
+        for k in range(1, last + 1):
+            self.run(k)
+
     def fix(self):
         """Some query patch, on some rank, had more near-ties than candidate slots (e.g. a uniform background against a
         bank of the same background): the marked queries of EVERY rank meet the whole bank again through the exhaustive
@@ -762,8 +881,8 @@ def alpha_weights_supervised(ops, pk_loc, pk_bank_loc, bank_bounds, rank, world,
             dist.all_reduce(job.mq, op=dist.ReduceOp.MAX, group=group)
         job.prepare()
         job.post()
-        for k in range(world):                      # the whole ring is queued without a host read
-            job.run(k)
+        job.run(0)                                  # the whole ring is queued without a host read
+        job.run_later()
         # ONE host read per search: did any query patch, on any bank shard, have more near-ties than candidate slots?
         # On ordinary data: no, and this is all.  Otherwise those queries - on every rank, hence the MAX all-reduce of
         # the flag: the ring is collective - take the exhaustive path (fix).  A bank on which every query overflows
@@ -1173,13 +1292,12 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
                     for c in grp:                      # no remote data needed: the first transfers hide under ALL of these
                         jobs[c].run(0)
                     for c in grp:
-                        for step in range(1, jobs[c].last_step + 1):
-                            jobs[c].run(step)
+                        jobs[c].run_later()
                 else:
                     for c in grp:
                         jobs[c].post()
-                        for step in range(0, jobs[c].last_step + 1):
-                            jobs[c].run(step)
+                        jobs[c].run(0)
+                        jobs[c].run_later()
                         jobs[c].ring = None
                 if sup:
                     if world > 1:

@@ -39,11 +39,19 @@ class LocalRing:
     TAPS (what the ring carries since round 4), which get() turns into a packed block exactly as the real ring does
     (aggregate + pack: part of the measured compute), or of its packed embeddings (--payload packed)."""
 
+    contig = True          # like a ring whose steps were all posted up front: a run of steps is one block (get_run)
+    pending = ()
+
     def __init__(self, ops, src, bounds, taps, rank=0):
         self.ops, self.src, self.bounds, self.taps, self.rank = ops, src, bounds, taps, rank
 
     def get(self, k):
-        lo, hi = self.bounds[(self.rank + k) % len(self.bounds)]
+        return self.get_run(k, k)
+
+    def get_run(self, k1, k2):
+        """Steps k1 .. k2 never wrap round image 0 inside one run (merge_later_steps), so they are one slice."""
+        G = len(self.bounds)
+        lo, hi = self.bounds[(self.rank + k1) % G][0], self.bounds[(self.rank + k2) % G][1]
         if hi <= lo:
             return None
         blk = self.src.slice(lo, hi)
@@ -129,8 +137,8 @@ def main():
                 te, z = timed(lambda: ops.embed(shards[c]))
                 def alpha():
                     jobs = jobs_for_one(c, z)
-                    for k in range(steps + 1):
-                        jobs.run(k)
+                    jobs.run(0)
+                    jobs.run_later()
                     w = jobs.finish()
                     _, a32 = ops.alpha_softmax(w, 1.0, 1)
                     ops.weighted_avg(a32, z)
@@ -155,7 +163,7 @@ def main():
             t0s, _ = timed(lambda: [jobs[c].run(0) for c in cats])        # step 0 of all categories
             later = []
             for c in cats:                                                # steps >= 1, category by category
-                tc, _ = timed(lambda: [jobs[c].run(k) for k in range(1, steps + 1)])
+                tc, _ = timed(lambda: jobs[c].run_later())
                 later.append(tc)
             tt, _ = timed(lambda: tail(jobs, Z))
             return te, tp, t0s, later, tt

@@ -70,7 +70,10 @@ class ToyOps:
             return torch.zeros(ncols, dtype=torch.int64)
         return torch.full((ncols,), INF_BITS, dtype=torch.int32)
 
+    launches = 0          # pair_block calls of this process (the eight-rank test counts them)
+
     def pair_block(self, keys, queries, two_way=False, part=0, nparts=1):
+        ToyOps.launches += 1
         P = keys.P
         same = keys.hl.data_ptr() == queries.hl.data_ptr() and keys.n == queries.n
         Zk, Zq = keys.hl.reshape(keys.n, P, -1), queries.hl.reshape(queries.n, P, -1)
@@ -527,22 +530,32 @@ def _worker_eight(rank, world, init_file, out_dir, mode, many):
     if rank in (0, 5, 7):
         for c, o in enumerate(outs):
             np.save(os.path.join(out_dir, "alpha_%d_%d.npy" % (rank, c)), o["alpha"].numpy())
+    np.save(os.path.join(out_dir, "launches_%d.npy" % rank), np.array([ToyOps.launches]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,many", [("unsupervised", False), ("supervised", False), ("unsupervised", True)])
-def test_eight_ranks_as_the_driver_will_launch_them(mode, many):
+@pytest.mark.parametrize("mode,many,merge", [("unsupervised", False, "1"), ("unsupervised", False, "0"), ("supervised", False, "1"),
+                                             ("supervised", False, "0"), ("unsupervised", True, "1")])
+def test_eight_ranks_as_the_driver_will_launch_them(mode, many, merge, monkeypatch):
     """World size 8 - what `bench.py --gpus 8` runs - over gloo with the taps ring: 19 images give the shards 3 3 3 3 3 3 1 0
     (a short one and an EMPTY one), four ring steps with the split step 4 (unsupervised), seven bank-shard steps and an
-    overflow raised on rank 3 only (supervised), rotated shards over three categories (many).  Equal to one rank."""
+    overflow raised on rank 3 only (supervised), rotated shards over three categories (many).  Equal to one rank - with the
+    later ring steps fused into rectangles (round 6: pipeline.merge_later_steps; the ranks of the lower half then run TWO
+    launches, their own triangle and one rectangle) and step by step (AC_RING_MERGE=0)."""
     from patchcore.pipeline import run_category
+    monkeypatch.setenv("AC_RING_MERGE", merge)
     g = torch.Generator().manual_seed(31)
     images, train = torch.randn(19, 3, 16, 16, generator=g), torch.randn(21, 3, 16, 16, generator=g)
     sets = [(images, train), (images[:5], train[:9]), (images[3:16], train[2:])] if many else [(images, train)]
     ref = [run_category(ToyOps(), a, mode, tau=1.0, train_images=b, train_ratio=1.0) for a, b in sets]
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_eight, args=(8, os.path.join(d, "rdzv"), d, mode, many), nprocs=8, join=True)
+        if mode == "unsupervised" and not many:
+            n_launch = [int(np.load(os.path.join(d, "launches_%d.npy" % r))[0]) for r in range(8)]
+            # shards 3 3 3 3 3 3 1 0.  Step by step: own triangle + one block per step with a non-empty partner.  Fused: ranks 0-3
+            # one rectangle; rank 4 (5, 6 | its last image x 0), 5 (6 | 0 | its last image x 1) two and three, rank 6 (one image: 0, 1) one; rank 7 is empty.
+            assert n_launch == ([2, 2, 2, 2, 3, 4, 2, 0] if merge == "1" else [5, 5, 5, 4, 4, 4, 3, 0]), n_launch
         for rk in (0, 5, 7):
             for c, r in enumerate(ref):
                 a = np.load(os.path.join(d, "alpha_%d_%d.npy" % (rk, c)))

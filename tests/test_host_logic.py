@@ -134,6 +134,41 @@ def test_unsupervised_block_schedule_covers_every_pair_once():
     assert block_images(784, 1 << 30) == 585 and block_images(784, 100) == 1
 
 
+def test_later_ring_steps_fuse_into_rectangles():
+    """pipeline.merge_later_steps: the blocks of ring steps >= 1 fused into as few two-way rectangles as their shapes
+    allow.  Over all ranks the fused launches still cover every pair of images from different shards exactly once; a fused
+    block never crosses image 0 (its remote images are one ascending range on ONE side of the local block - the
+    orientation rule), stays inside the block limits, and the count of launches is what DESIGN.md section 6 says: ONE per rank of
+    the lower half of an even world, at most three in the upper half."""
+    from patchcore.pipeline import unsup_schedule, merge_later_steps, shard_bounds
+    P = 784
+    for n in (5, 16, 83, 167):
+        for world in (2, 3, 4, 5, 8):
+            for c in (3, 1000):
+                b = shard_bounds(n, world)
+                cov = np.zeros((n, n), int)
+                for r in range(world):
+                    items = [it for it in unsup_schedule(b, r, c) if it[1] >= 1]
+                    fused = merge_later_steps(items, c, P)
+                    for _, (k1, k2), (a0, a1), (b0, b1) in fused:
+                        assert 1 <= k1 <= k2 <= world // 2 and b[r][0] <= a0 < a1 <= b[r][1]
+                        assert b1 - b0 <= c and a1 - a0 <= c
+                        # the remote images: one ascending range starting inside the shard of step k1, ending inside that of k2
+                        s1, s2 = b[(r + k1) % world], b[(r + k2) % world]
+                        assert s1[0] <= b0 < s1[1] and s2[0] < b1 <= s2[1] and b0 < b1
+                        assert (b0 >= a1) or (b1 <= a0)                      # wholly on one side of the local block
+                        cov[a0:a1, b0:b1] += 1
+                        cov[b0:b1, a0:a1] += 1
+                    if c == 1000 and n >= world:
+                        assert len(fused) <= (1 if (world % 2 == 0 and r < world // 2) or world <= 3 else 3), (n, world, r, fused)
+                for r in range(world):                                       # what step 0 covers: pairs inside one shard
+                    cov[b[r][0]:b[r][1], b[r][0]:b[r][1]] += 1
+                assert (cov == 1).all(), (n, world, c)
+    # a fused block that would not fit the matrix-of-minima budget is left in pieces
+    items = [("two", 1, (0, 10), (10, 20)), ("two", 2, (0, 10), (20, 30))]
+    assert len(merge_later_steps(items, 1000, P)) == 1 and len(merge_later_steps(items, 1000, P, budget=10 * 15 * P * 4)) == 2
+
+
 def test_artefact_paths_match_reference_scheme():
     main, test_mod = _examples()
     d = main.artefact_dir("outputs/mvtec_ad/dino_vitbase8/unsupervised", ["blocks.10", "blocks.11"], 2048, 4096, 2, 1)

@@ -59,15 +59,19 @@ def _worker(rank, world, init_file, mode, out_dir, lean=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["unsupervised", "supervised"])
-def test_two_ranks_on_one_gpu_match_one_rank(dev, mode):
+@pytest.mark.parametrize("mode,world", [("unsupervised", 2), ("supervised", 2), ("unsupervised", 4), ("supervised", 4)])
+def test_two_ranks_on_one_gpu_match_one_rank(dev, mode, world):
+    """world = 4 (shards of 2 2 2 1 images, bank 2 2 1 0): the first size at which the ring has more than one later step, so
+    the fused path runs on the real kernels (round 6, pipeline.merge_later_steps / _Ring.get_run: the received taps of
+    steps 1 and 2 side by side in one store, ONE aggregation + pack, one two-way rectangle - or, for the ranks whose ring
+    wraps round image 0, two; supervised: the three remote bank shards as one key block, one scan)."""
     from patchcore.pipeline import HipOps, run_category
     core = _build(dev)
     test, train = _images()
     ref = run_category(HipOps(core, batch_size=4), test.to(dev), mode, tau=1.0, train_images=train.to(dev))
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, os.path.join(d, "rdzv"), mode, d), nprocs=2, join=True)
-        for r in range(2):
+        mp.spawn(_worker, args=(world, os.path.join(d, "rdzv"), mode, d), nprocs=world, join=True)
+        for r in range(world):
             a = np.load(os.path.join(d, "alpha_%d.npy" % r))
             X = np.load(os.path.join(d, "X_%d.npy" % r))
             # the ring carries the ViT taps here (HipOps with a backbone): the receiver re-aggregates and packs them.
