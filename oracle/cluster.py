@@ -57,6 +57,24 @@ def calculate_metrics(X, anomaly_names):
     return NMI, ARI, F1, label, predict
 
 
+def calculate_metrics_from_pdist(condensed, names):
+    """test.py:190-220 from the point where sklearn's AgglomerativeClustering hands over to scipy: ward_tree without
+    connectivity is scipy.cluster.hierarchy.ward on the float64 rows (= linkage(pdist(X), "ward")), children =
+    the first two columns, labels = sklearn's _hc_cut.  `condensed`: scipy-order float64 distances of the kept images
+    (tests/golden/kat_all_pdist.npz), `names`: their anomaly-type strings.  Returns NMI, ARI, F1, label, predict, Z."""
+    from scipy.cluster import hierarchy
+    from sklearn.cluster._agglomerative import _hc_cut
+    label = LabelEncoder().fit_transform(list(names)).astype(int)
+    n = len(label)
+    Z = hierarchy.linkage(np.asarray(condensed, dtype=np.float64), method="ward")
+    children = Z[:, :2].astype(np.intp)
+    predict = best_map(label, _hc_cut(len(set(label)), children, n)).astype(int)
+    NMI = metrics.normalized_mutual_info_score(label, predict)
+    ARI = metrics.adjusted_rand_score(label, predict)
+    F1 = metrics.f1_score(label, predict, average="micro")
+    return NMI, ARI, F1, label, predict, Z
+
+
 def pdist(X):
     """scipy pdist as called inside scipy.cluster.hierarchy.ward (via sklearn
     ward_tree, test.py:193-195): condensed Euclidean distances in float64."""

@@ -10,6 +10,7 @@ from tests/_synth.py, and stores what they return.  Stored: outputs only
 (plus per-tensor checksums of the seed-0 weights); no reference source.
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden/make_golden.py --kat-all  # kat_all_pdist.npz: all 26 committed (alpha, X) artefacts (data files only)
 """
 import csv
 import os
@@ -284,8 +285,51 @@ def known_answer_rows():
             print("KAT", cat, mode, X.shape, rows[("2", cat)])
 
 
+def known_answer_rows_all():
+    """G5, complete (round 6): EVERY (alpha, X) artefact the reference commits - 13 categories x {unsupervised, supervised}
+    at tau = 2 (pill and screw have none) - as what the cluster stage starts from: the condensed float64 Euclidean
+    distances of the kept images (scipy's pdist on the float64 X, "combined" images dropped: examples/test.py:176-195),
+    their anomaly-type strings and the reference's CSV row.  One file, derived arrays only (the three kat_*.npz above
+    keep the full X for the pdist kernel)."""
+    import numpy
+    from scipy.spatial.distance import pdist
+    allow = [numpy.ndarray, numpy.dtype, type(numpy.dtype("float32")),
+             (numpy._core.multiarray._reconstruct, "numpy.core.multiarray._reconstruct")]
+    outdir = os.path.join(REF, "outputs/mvtec_ad")
+    out, n_rows = {}, 0
+    for mode in ("unsupervised", "supervised"):
+        rows, tau = {}, None
+        with open(os.path.join(outdir, "dino_vitbase8", mode, "blocks.10_blocks.11_2048_4096_tau_result.csv"), encoding="gbk") as f:
+            for r in csv.reader(f):
+                if r and r[0].startswith("TAU="):
+                    tau = r[0][4:]
+                elif tau is not None and len(r) == 4 and r[0] not in ("---", "Category"):
+                    rows[(tau, r[0])] = [float(v) for v in r[1:]]
+        folder = os.path.join(outdir, "dino_vitbase8", mode, "blocks.10_blocks.11_2048_4096_2.0_1.0")
+        for fn in sorted(os.listdir(folder)):
+            if not (fn.startswith("matrix_alpha_X_") and fn.endswith("_%s.pickle" % mode)):
+                continue
+            cat = fn[len("matrix_alpha_X_"): -len("_%s.pickle" % mode)]
+            with torch.serialization.safe_globals(allow):
+                _, X = torch.load(os.path.join(folder, fn), map_location="cpu", weights_only=True)
+            info = torch.load(os.path.join(outdir, "info", "info_%s.pickle" % cat), map_location="cpu", weights_only=True)
+            names = [d["anomaly"][0] for d in info]
+            keep = [i for i, a in enumerate(names) if a != "combined"]
+            X64 = np.asarray(X)[keep].astype(np.float64)
+            out["pdist_%s_%s" % (cat, mode)] = pdist(X64, metric="euclidean")
+            out["names_%s" % cat] = np.array([names[i] for i in keep])
+            out["expected_%s_%s" % (cat, mode)] = np.array(rows[("2", cat)])
+            n_rows += 1
+            print("KAT", cat, mode, X64.shape, rows[("2", cat)])
+    out["rows"] = np.array(sorted(k[len("pdist_"):] for k in out if k.startswith("pdist_")))
+    np.savez_compressed(os.path.join(HERE, "kat_all_pdist.npz"), **out)
+    print("known-answer rows:", n_rows)
+
+
 if __name__ == "__main__":
-    if "--a15" in sys.argv:
+    if "--kat-all" in sys.argv:
+        known_answer_rows_all()
+    elif "--a15" in sys.argv:
         a15_fixture()
     else:
         main(only_kat="--kat" in sys.argv, only_dino="--dino" in sys.argv)

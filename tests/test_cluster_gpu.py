@@ -95,3 +95,25 @@ def test_known_answer_rows_end_to_end_on_the_device(golden, dev, name):
     g = golden(name + ".npz")
     NMI, ARI, F1, label, predict = cluster_metrics(g["X"], list(g["anomaly"]), device=dev)
     np.testing.assert_allclose([NMI, ARI, F1], g["expected"], rtol=0, atol=1e-12)
+
+
+def test_all_26_known_answer_rows_on_the_device(golden, dev):
+    """every (alpha, X) artefact the reference commits - 13 categories x {unsupervised, supervised} - from the
+    condensed float64 distances of its kept images (tests/golden/kat_all_pdist.npz) through ac_ward_linkage -> cut -> relabel
+    -> ac_cluster_scores: the reference's CSV row to 1e-12, and the linkage matrix BIT-IDENTICAL to scipy's on the same
+    distances (merge order, ids, heights, sizes) - the Ward kernel's tie rules on 26 sets of real embeddings."""
+    import acnative
+    from scipy.cluster import hierarchy
+    from patchcore.clustering import cluster_metrics_from_pdist
+    g = golden("kat_all_pdist.npz")
+    rows = [str(r) for r in g["rows"]]
+    assert len(rows) == 26
+    for row in rows:
+        cat, mode = row.rsplit("_", 1)
+        names = [str(v) for v in g["names_" + cat]]
+        d_host = g["pdist_" + row]
+        d = torch.from_numpy(d_host).to(dev)
+        Z = acnative.ward_linkage(d, len(names)).cpu().numpy()
+        assert np.array_equal(Z, hierarchy.linkage(d_host, method="ward")), row
+        NMI, ARI, F1, label, predict = cluster_metrics_from_pdist(d, names)
+        np.testing.assert_allclose([NMI, ARI, F1], g["expected_" + row], rtol=0, atol=1e-12, err_msg=row)

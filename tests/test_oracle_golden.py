@@ -174,6 +174,29 @@ def test_known_answer_rows_from_reference_csv(golden, name):
     assert len(label) == sum(a != "combined" for a in g["anomaly"])
 
 
+def test_all_26_known_answer_rows_from_reference_csv(golden):
+    """EVERY (alpha, X) artefact the reference commits (13 categories x 2 modes at tau = 2): the condensed distances
+    of its kept images -> Ward -> cut -> Hungarian -> NMI / ARI / F1 = the reference's own CSV row, through the oracle.
+    Where the full X is committed too (three rows), both routes must give the same labels."""
+    from oracle import cluster as oc
+    g = golden("kat_all_pdist.npz")
+    rows = [str(r) for r in g["rows"]]
+    assert len(rows) == 26
+    for row in rows:
+        cat, mode = row.rsplit("_", 1)
+        names = [str(v) for v in g["names_" + cat]]
+        d = g["pdist_" + row]
+        assert d.dtype == np.float64 and d.shape == (len(names) * (len(names) - 1) // 2,) and "combined" not in names
+        NMI, ARI, F1, label, predict, _ = oc.calculate_metrics_from_pdist(d, names)
+        np.testing.assert_allclose([NMI, ARI, F1], g["expected_" + row], rtol=0, atol=1e-12, err_msg=row)
+    for name in ("toothbrush_unsupervised", "grid_unsupervised", "toothbrush_supervised"):
+        k = golden("kat_%s.npz" % name)
+        _, _, _, label_x, predict_x = oc.calculate_metrics(k["X"], list(k["anomaly"]))
+        cat = name.rsplit("_", 1)[0]
+        _, _, _, label_d, predict_d, _ = oc.calculate_metrics_from_pdist(g["pdist_" + name], [str(v) for v in g["names_" + cat]])
+        assert np.array_equal(label_x, label_d) and np.array_equal(predict_x, predict_d)
+
+
 def test_best_map_is_a_permutation_fix():
     from oracle.cluster import best_map
     L1 = np.array([0, 0, 1, 1, 2, 2, 2])
