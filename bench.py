@@ -96,10 +96,12 @@ def parse():
                          "rehearsal of the launcher and of every rank's code path with the real kernels, NOT a measurement - "
                          "the JSON line says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, nargs="+", default=[48],
-                    help="category sizes at which the CPU baseline is MEASURED (default: one bounded sample of N=48, about 16 s "
-                         "of host time, scaled to the workload's size by its per-image and per-pair costs; `--cpu-n 83` measures "
-                         "config 2's own size: about 40 s)")
+    ap.add_argument("--cpu-n", type=int, nargs="+", default=None,
+                    help="category sizes at which the CPU baseline is MEASURED.  Default: the workload's own category size when it "
+                         "is one category (config 2: N=83, about 40 s of host time at the best thread count - BASELINE.md section 3 "
+                         "asks for the measured figure), else one bounded sample of N=48 scaled to a mid-size category by its "
+                         "per-image and per-pair costs (`scaled: true` in the record).  `--cpu-n 48`: the bounded sample for "
+                         "config 2 as well (about 16 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip images_resident / ward_metrics_ms / stage_ms")
     return ap.parse_args()
 
@@ -130,17 +132,25 @@ def pmc_traffic(workload_key, kernel_substr):
     return best
 
 
+BUILD_HEAD_FILE = os.path.join(ROOT, "anomaly-clustering_amd", "models", "acnative", "BUILD_HEAD")
+
+
 def git_head():
-    """Short hash of the checked-out commit (+ "-dirty"), or None outside a work tree (the GPU box has no .git)."""
+    """Short hash of the checked-out commit (+ "-dirty").  Outside a work tree - the GPU box gets a snapshot without
+    .git - the hash that __graft_entry__.build() wrote next to the library it built (BUILD_HEAD: generated, git-ignored,
+    travels with the snapshot like the .so); None only when neither exists."""
     import subprocess
     try:
         h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
-        if h.returncode != 0:
-            return None
-        d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
-                           timeout=10)
-        return h.stdout.strip() + ("-dirty" if d.stdout.strip() else "")
+        if h.returncode == 0 and h.stdout.strip():
+            d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
+                               timeout=10)
+            return h.stdout.strip() + ("-dirty" if d.stdout.strip() else "")
     except Exception:
+        pass
+    try:
+        return open(BUILD_HEAD_FILE).read().split()[0]
+    except (OSError, IndexError):
         return None
 
 
@@ -262,7 +272,8 @@ def cpu_baseline(sizes, n_quote, category, probe_n=8):
         runs.append({"n": len(lab), "images_per_sec": len(lab) / (e + a + t), "seconds": e + a + t,
                      "s_per_image": (e + t) / len(lab), "s_per_pair": a / max(1, len(lab) * (len(lab) - 1))})
     torch.set_num_threads(1)
-    e1, a1, t1 = _cpu_run(sd, probe, 3)
+    n_one = min(8, probe.shape[0])                         # (rounds 4-5: 3 images; BASELINE.md section 3 asks for a one-thread leg)
+    e1, a1, t1 = _cpu_run(sd, probe, n_one)
     torch.set_num_threads(default_threads)
     at_size = [r for r in runs if r["n"] == n_quote]
     head = at_size[0] if at_size else runs[-1]
@@ -278,15 +289,19 @@ def cpu_baseline(sizes, n_quote, category, probe_n=8):
                         "is too small to feed them." % (best, worse)) if worse else ""))
     out = {"value": head["images_per_sec"], "unit": "images/sec", "cores": best, "threads": best, "kind": "port",
            "sample": "MEASURED: %s at %s" % (what, threads_note),
+           "scaled": False,
            "n": head["n"], "seconds": head["seconds"], "s_per_image": head["s_per_image"], "s_per_pair": head["s_per_pair"],
            "measured_sizes": runs,
-           "one_thread": {"n": 3, "images_per_sec": 3 / (e1 + a1 + t1), "seconds": e1 + a1 + t1},
+           "one_thread": {"n": n_one, "images_per_sec": n_one / (e1 + a1 + t1), "seconds": e1 + a1 + t1,
+                          "s_per_image": (e1 + t1) / n_one, "s_per_pair": a1 / max(1, n_one * (n_one - 1))},
            "nproc": nproc, "physical_cores": _physical_cores(), "cpu_model": _cpu_model(),
            "torch_default_threads": default_threads}
     if not at_size:                                # a bounded sample, scaled to the workload's own N (alpha is O(N^2))
+        # n / seconds / s_per_* stay those of the MEASURED run; the scaled figure says so in its own fields
+        out["scaled"] = True
+        out["scaled_to_n"] = n_quote
         out["measured_sample"] = {"n": head["n"], "images_per_sec": head["images_per_sec"], "seconds": head["seconds"]}
         out["value"] = n_quote / (n_quote * head["s_per_image"] + n_quote * (n_quote - 1) * head["s_per_pair"])
-        out["n"] = n_quote
         out["sample"] = ("SCALED to the workload's N=%d (value = N / (N * s_per_image + N(N-1) * s_per_pair)) from a MEASURED sample: "
                          "%s at %s" % (n_quote, what, threads_note))
     return out
@@ -718,7 +733,10 @@ def main():
                                  "note": "mean over the step's categories, synthetic labels (not part of the metric)"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, len(items[0]["labels"]) if len(items) == 1 else 115,
+            n_quote = len(items[0]["labels"]) if len(items) == 1 else 115
+            # one category of MVTec size: measured at its own N; several categories / a synthetic 10 000: the bounded sample
+            sizes = args.cpu_n or ([n_quote] if len(items) == 1 and n_quote <= 200 else [48])
+            out["cpu_baseline"] = cpu_baseline(sizes, n_quote,
                                                items[0]["category"] if items[0]["category"] in ("bottle", "pill") else "bottle")
         print(json.dumps(out))
     if world > 1:
