@@ -339,9 +339,11 @@ struct EpiPairMin {
 };
 template <> struct gemm::EpiTraits<EpiPairMin> { static constexpr bool kSymmetric = true; static constexpr bool kStaged = false; };
 
-// The all-pairs kernel is gemm_hl2.h's 256x128 ring kernel with two-level accumulation (FLUSH): the only tile
-// whose per-wave state leaves room for the second accumulator that fp32-grade distances need (DESIGN.md
-// section 2; the 256x256 stream without it is 10 % faster and 6x further from the fp64 truth).
+// The all-pairs kernel: gemm_hl7.h's 256x192 tile on eight waves with two-level accumulation (round 5: the largest tile
+// whose per-wave state - two accumulator sets, which fp32-grade distances need - fits 256 registers; DESIGN.md sections
+// 2 and 4; the 256x256 stream without the second accumulator is 10 % faster and 6x further from the fp64 truth).
+// gemm_hl2.h's 256x128 ring kernel with the same accumulation (FLUSH), the kernel of rounds 1-4, stays as the pinned
+// fallback (ac_set_gemm_policy(AC_GEMM_256x128)); the two agree to the bit.
 // L2 window of the rasterisation: 6 tile rows per group (the 32 workgroups an XCD runs at a time then share 6 row
 // panels and ~6 column panels); same-box A/B over 2..16 rows and two tile orders: profiles/r02_raster_ab.txt.
 static int launch_pair_min(const void* A, const void* B, int M, int N, int K, const EpiPairMin& epi, hipStream_t stream,

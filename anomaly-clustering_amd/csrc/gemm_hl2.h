@@ -184,7 +184,7 @@ __host__ __device__ inline void tri_tile(int lin, int Tm, int Tn, int G, int& tm
   tn = 2 * p0 + c;
 }
 
-__device__ inline int xcd_chunk_lin(int id, long long total) {
+__host__ __device__ inline int xcd_chunk_lin(int id, long long total) {
   return gemm::xcd_lin<AC_XCD_WINDOW_TRI>(id, total);
 }
 

@@ -325,6 +325,16 @@ class HipOps:
             self._zshape = tuple(self.core.embed_device(probe, batch_size=1).shape[1:])
         return self._zshape
 
+    def never_lean(self, n_images):
+        """True when Z + packed of n_images is so small (an eighth of the device's TOTAL memory: 36 GB on an MI355X, 1 400
+        images) that no rank of the job can want the lean mode whatever its free HBM is.  A function of the shapes and of
+        the device model only - every rank of a run on one kind of GPU gets the same answer without asking the others
+        (run_categories: no all-reduce and no host read in a steady-state step of configs 3 / 4 on several ranks)."""
+        if self.core is None:
+            return True
+        P, D = self.zshape()
+        return n_images * 2 * P * D * 4 <= torch.cuda.get_device_properties(self.core.device).total_memory // 8
+
     def wants_lean(self, n_images):
         """Lean when Z + packed of n_images would not fit comfortably - and the backbone's taps can be kept at all (token
         maps; the channels-last views of the CNN branch cannot, and its categories are small)."""
@@ -1124,7 +1134,7 @@ def _groups(sizes, limit):
 def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ratio=1.0, group=None, bank_seed=0,
                    want_pdist=True, want_host=True, timings=None, budget=MINBUF_BYTES, remote_bytes=REMOTE_BYTES,
                    prune=True, schedule="pipeline", group_images=GROUP_IMAGES, ring_bytes_all=RING_BYTES_ALL,
-                   costs=None, solo=False, Z_locs=None, rotate=True):
+                   costs=None, solo=False, Z_locs=None, rotate=True, lean=None):
     """Several categories as ONE job.  items: [{"images": [N_c, 3, H, W], "train_images": bank candidates or None}].
     Returns [run_category's dict per category]; the numbers are those of the per-category loop the reference runs
     (examples/main.py:346-366) - bit for bit given the same embeddings - only the ORDER of the work changes:
@@ -1150,7 +1160,11 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
     Z_locs: the rank's test-set embeddings of EVERY category from an earlier call (out[c]["Z_loc"]; "pipeline" and
     "sequential" only): a second mode on the same images embeds only its bank.
     rotate ("pipeline"): category c is sharded with rotation category_rot(c, world) (see run_category's `rot`): a caller
-    that loads only its own shard of the images must load that of virtual rank (rank + category_rot(c, world)) % world."""
+    that loads only its own shard of the images must load that of virtual rank (rank + category_rot(c, world)) % world.
+    lean ("pipeline"): None - every group decides from the rank's free HBM, the ranks agreeing by one MAX all-reduce and one
+    host read per group unless the group is too small to matter (HipOps.never_lean); False / True - the caller has decided
+    (every rank must pass the same value): no query, no collective, no host read (bench.py decides once, before its
+    timed steps)."""
     rank, world = (0, 1) if solo else _world(group)
     mark = _marker(ops, timings)
     ncat = len(items)
@@ -1197,12 +1211,16 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
         # run_category, which has the lean path; the one-job order below holds full Z.  Every rank must take the same
         # branch (the two orders post different collectives), so the ranks agree on the flag first.  (Round-4 advice: the
         # one-job path used to read Z_locs[c].shape of a Taps object and to embed large groups with full Z.)
-        lean_grp = Z_locs is not None and any(isinstance(Z_locs[c], Taps) for c in grp)
-        lean_grp = lean_grp or bool(getattr(ops, "wants_lean", lambda _n: False)(sum(per_rank[c] for c in grp)))
-        if world > 1:
-            flag = torch.tensor([int(lean_grp)], dtype=torch.int32, device=_flag_device(ops, items[grp[0]]["images"]))
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            lean_grp = bool(int(flag.item()))
+        lean_grp = Z_locs is not None and any(isinstance(Z_locs[c], Taps) for c in grp)      # (the same on every rank)
+        grp_images = sum(per_rank[c] for c in grp)                                           # test + bank images of the largest shards
+        if lean is not None:
+            lean_grp = lean_grp or bool(lean)
+        elif not lean_grp and not getattr(ops, "never_lean", lambda _n: False)(grp_images):
+            lean_grp = bool(getattr(ops, "wants_lean", lambda _n: False)(grp_images))
+            if world > 1:
+                flag = torch.tensor([int(lean_grp)], dtype=torch.int32, device=_flag_device(ops, items[grp[0]]["images"]))
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                lean_grp = bool(int(flag.item()))
         if lean_grp:
             for c in grp:
                 outs[c] = one(c, rots[c])

@@ -158,24 +158,34 @@ class HostFeeder:
     """The images (and bank images) of every step start in PINNED HOST memory.  A copy stream moves the images of step
     k + 1 into the second of two device buffers while step k computes; a step waits for the event of ITS copy.  The first
     step of a run finds nothing prefetched and pays its copy in full; `more` = False on the last step of a run (no copy for
-    a step that will not happen)."""
+    a step that will not happen).
+    shards[i] = (lo, hi): of item i's TEST images only rows [lo, hi) - the shard this rank reads (run_category /
+    run_categories slice exactly images[lo:hi]) - are copied, and the step gets a ShardView over them; None: all rows.  (Round 5
+    copied every category whole on every rank: 8 ranks moved 8x what the step consumes, from one host memory.)  The bank
+    candidates (`train_host`, config 4) travel whole: the rank's bank shard is a seeded SELECTION of them."""
 
-    def __init__(self, items, dev):
+    def __init__(self, items, dev, shards=None):
         self.items, self.dev = items, dev
+        self.shards = shards or [None] * len(items)
         self.stream = torch.cuda.Stream(dev)
         keys = [k for k in ("images_host", "train_host")]
         self.keys = keys
-        self.bufs = [[{k: torch.empty(it[k].shape, dtype=it[k].dtype, device=dev) for k in keys if it.get(k) is not None}
-                      for it in items] for _ in range(2)]
+
+        def buf(it, k, sh):
+            rows = it[k].shape[0] if (sh is None or k != "images_host") else sh[1] - sh[0]
+            return torch.empty((rows,) + tuple(it[k].shape[1:]), dtype=it[k].dtype, device=dev)
+        self.bufs = [[{k: buf(it, k, sh) for k in keys if it.get(k) is not None} for it, sh in zip(items, self.shards)]
+                     for _ in range(2)]
         self.ev = [None, None]
         self.k = 0
 
     def _start(self, slot):
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))     # the step that read this buffer last is queued in front
         with torch.cuda.stream(self.stream):
-            for b, it in zip(self.bufs[slot], self.items):
+            for b, it, sh in zip(self.bufs[slot], self.items, self.shards):
                 for k, t in b.items():
-                    t.copy_(it[k], non_blocking=True)
+                    src = it[k] if (sh is None or k != "images_host") else it[k][sh[0]:sh[1]]
+                    t.copy_(src, non_blocking=True)
             self.ev[slot] = torch.cuda.Event()
             self.ev[slot].record(self.stream)
 
@@ -188,7 +198,13 @@ class HostFeeder:
         self.k += 1
         if more:
             self._start(slot ^ 1)                                        # the next step's images travel under this step
-        return self.bufs[slot]
+        out = []
+        for b, it, sh in zip(self.bufs[slot], self.items, self.shards):
+            d = dict(b)
+            if sh is not None:
+                d["images_host"] = ShardView(it["images_host"].shape[0], sh[0], sh[1], b["images_host"])
+            out.append(d)
+        return out
 
 
 # ------------------------------------------------------------------ CPU baseline (oracle = port of the reference)
@@ -570,7 +586,13 @@ def main():
 
     many = len(items) > 1 and args.category_schedule != "sequential"
     can_feed = all(it.get("images_host") is not None for it in items)      # config 5 keeps its (sharded) images resident
-    feeder = HostFeeder(items, dev) if can_feed else None
+    feed_shards = None
+    if can_feed and world > 1 and (not many or args.category_schedule == "pipeline"):
+        # the rows this rank reads: its shard - of the virtual rank run_categories' rotation gives it for category i
+        from patchcore.pipeline import shard_bounds, category_rot
+        feed_shards = [shard_bounds(len(it["labels"]), world)[(rank + (category_rot(i, world) if many else 0)) % world]
+                       for i, it in enumerate(items)]
+    feeder = HostFeeder(items, dev, feed_shards) if can_feed else None
     if args.lean == "auto" and len(items) == 1:
         # decided ONCE, before any step: the seam decides from the free HBM of the moment, and a warm-up step whose result is
         # still alive could otherwise take another path than the timed ones (round-4 advice)
@@ -583,7 +605,7 @@ def main():
             its = [{"images": fed[i]["images_host"] if from_host else it["images"],
                     "train_images": (fed[i].get("train_host") if from_host else it.get("train"))} for i, it in enumerate(items)]
             outs = run_categories(ops, its, mode, tau=args.tau, train_ratio=1.0, want_host=False, timings=timings,
-                                  budget=budget, schedule=args.category_schedule)
+                                  budget=budget, schedule=args.category_schedule, lean=lean)
             for o in outs:                                  # Z (12.85 MB per image) is not part of the result kept
                 o["lean"] = not isinstance(o.pop("Z_loc", None), torch.Tensor)
             return outs

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same process, same library, interleaved: a ViT-B/8 forward (12 blocks) with LayerNorm inside the residual GEMMs
-(EpiResidual::tail, csrc/vit.hip; the default) against the separate LayerNorm launches (ac_set_ln_fusion(0)).
+(EpiResidual::tail of the patched csrc/vit.hip) against the separate LayerNorm launches (ac_set_ln_fusion(0)).
 Outputs compared bit for bit every round.  NEEDS scratch/exp_layernorm_in_residual_gemm.patch applied (the shipped library has
 no ac_set_ln_fusion: the experiment was bit-equal and slower - profiles/r05_vit_layernorm_in_residual_gemm_ab.txt).
 
@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", type=int, default=None, help="0 / 1: run only that mode (per-kernel times under rocprofv3)")
     a = ap.parse_args()
+    if not hasattr(acnative, "set_ln_fusion"):
+        sys.exit("ab_ln_fusion: this library has no ac_set_ln_fusion - apply scratch/exp_layernorm_in_residual_gemm.patch and rebuild "
+                 "(the experiment did not ship: profiles/r05_vit_layernorm_in_residual_gemm_ab.txt)")
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     m = vits.vit_base(patch_size=8, num_classes=0).eval().to(dev)

@@ -1,6 +1,8 @@
 # gpurun -- bash scratch/ln_fusion_kernel_stats.sh : per-kernel times of a ViT-B/8 forward at 83 images (12 blocks) under
-# `rocprofv3 --kernel-trace --stats`, same box, for: LayerNorm inside the residual GEMMs (product), separate launches
-# (product, ac_set_ln_fusion(0)), and diagnostic builds given as name=lib:mode (mode 0 separate / 1 fused).
+# `rocprofv3 --kernel-trace --stats`, same box, for: LayerNorm inside the residual GEMMs against separate launches.
+# NEEDS A LIBRARY BUILT WITH scratch/exp_layernorm_in_residual_gemm.patch APPLIED (it adds ac_set_ln_fusion): the experiment was
+# bit-equal and slower and did NOT ship (profiles/r05_vit_layernorm_in_residual_gemm_ab.txt) - the product library has no such
+# entry point, and scratch/ab_ln_fusion.py stops with a message on it.  Further builds as name=lib:mode (mode 0 separate / 1 fused).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 L=$R/anomaly-clustering_amd/models/acnative

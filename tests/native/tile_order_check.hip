@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
       gemm7::TriCache tc;
       for (int id = 0; id < total; ++id) {                       // block ids in launch order
         int tm = -1, tn = -1;
-        gemm7::tri_tile(gemm::xcd_lin<AC_XCD_WINDOW_TRI>(id, total), Tm, Tn, G, tm, tn, tc);
+        gemm7::tri_tile(gemm2::xcd_chunk_lin(id, total), Tm, Tn, G, tm, tn, tc);   // the kernels' own id -> position map
         if (!need.count({tm, tn}) || !seen.insert({tm, tn}).second) { printf("FAIL M=%d G=%d id=%d -> (%d, %d)\n", M, G, id, tm, tn); return 1; }
       }
       gemm7::TriCache t2;
@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
       std::set<std::pair<int, int>> seen;
       for (int id = 0; id < total; ++id) {
         int tm = -1, tn = -1;
-        gemm2::tri_tile(gemm::xcd_lin<AC_XCD_WINDOW_TRI>(id, total), Tm, Tn, G, tm, tn);
+        gemm2::tri_tile(gemm2::xcd_chunk_lin(id, total), Tm, Tn, G, tm, tn);
         if (tm < 0 || tm >= Tm || tn < 2 * tm || tn >= Tn || !seen.insert({tm, tn}).second) { printf("FAIL hl2 M=%d id=%d\n", M, id); return 1; }
       }
     }
