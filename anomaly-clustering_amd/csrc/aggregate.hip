@@ -88,6 +88,7 @@ struct AggParams {
   int n_layers, k, pre, tgt, H0, W0;
   float eps;
   float* Z;
+  uint8_t* Zhl;           // register path only (ac_patch_aggregate_hl32): the rows leave as hl32 instead of fp32
 };
 
 // torch's area_pixel_compute_source_index for bilinear, align_corners=False
@@ -267,6 +268,10 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_kernel(AggParams prm) {
 // from L2.
 struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 
+// HL: the 8 outputs of a thread leave as hl32 (16 bytes of hi halves + 16 of lo halves into the row's 128-byte group: the split
+// pack_hl32_kernel would make of the same fp32 values, so the same bytes) - round 6: the shards a rank RECEIVES over the ring
+// are only ever multiplied, their fp32 Z (12.85 MB per image written, then read back by the pack kernel) need not exist.
+template <bool HL>
 __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_kernel(AggParams prm) {
   const int t = threadIdx.x;
   const int patch = xcd_local_patch(blockIdx.x, gridDim.x), b = blockIdx.y, l = blockIdx.z;   // one layer per workgroup:
@@ -301,9 +306,14 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_kernel(AggParams prm
       if (i >= s && i < e) acc += v[i];
     out[q] = (e - s) == 4 ? acc * 0.25f : acc / (float)(e - s);            // x / 4 == x * 0.25 exactly
   }
-  float* o = prm.Z + ((size_t)b * prm.H0 * prm.W0 + patch) * prm.tgt + l * prm.pre + 8 * t;
-  *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
-  *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+  const size_t row = (size_t)b * prm.H0 * prm.W0 + patch;
+  if constexpr (HL) {
+    store_hl32_8(prm.Zhl + row * prm.tgt * 4, l * prm.pre + 8 * t, out);
+  } else {
+    float* o = prm.Z + row * prm.tgt + l * prm.pre + 8 * t;
+    *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+  }
 }
 
 // ---- the same, one workgroup per ROW of patches (round 4).  Adjacent patches share six of their nine neighbour tokens:
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_kernel(AggParams prm
 // bit-identical.  Columns are kept in four named register sets rotated by a 4-step unrolled loop (no copies); the loads
 // of column x + 2 fly while patch x is summed.  Small batches (a rank's 11 images) keep one workgroup per patch: a row
 // per workgroup would leave the chip a third full.
+template <bool HL>
 __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_row_kernel(AggParams prm) {
   const int t = threadIdx.x;
   const int y = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
@@ -356,9 +367,14 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_row_kernel(AggParams
         if (i >= s && i < e) acc += v[i];
       out[q] = (e - s) == 4 ? acc * 0.25f : acc / (float)(e - s);            // x / 4 == x * 0.25 exactly
     }
-    float* o = prm.Z + ((size_t)b * prm.H0 * prm.W0 + (size_t)y * prm.W0 + x) * prm.tgt + l * prm.pre + 8 * t;
-    *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
-    *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+    const size_t row = (size_t)b * prm.H0 * prm.W0 + (size_t)y * prm.W0 + x;
+    if constexpr (HL) {
+      store_hl32_8(prm.Zhl + row * prm.tgt * 4, l * prm.pre + 8 * t, out);
+    } else {
+      float* o = prm.Z + row * prm.tgt + l * prm.pre + 8 * t;
+      *reinterpret_cast<f32x4*>(o) = f32x4{out[0], out[1], out[2], out[3]};
+      *reinterpret_cast<f32x4*>(o + 4) = f32x4{out[4], out[5], out[6], out[7]};
+    }
   };
   // four column sets: the loads of column x + 2 are in flight while patch x is summed and stored
   float ca[3][3], cb[3][3], cc[3][3], cd[3][3];
@@ -385,11 +401,50 @@ extern "C" size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C,
          align_up((size_t)n_layers * B * kStatChunks * 2 * sizeof(double), 256) + 256;
 }
 
+// The register path's shape test (both entry points): every layer a token map on the reference grid, K = 3,
+// 3 * pre == 8 * C per layer, identity final pool.
+static bool agg_is_reg27(const int* kind, const int* C, const int* H, const int* W, int n_layers, int patchsize, int pre_dim,
+                         int tgt_dim) {
+  bool ok = n_layers >= 1 && n_layers <= 4 && patchsize == 3 && (long long)n_layers * pre_dim == tgt_dim && pre_dim % 8 == 0 &&
+            pre_dim / 8 <= 256 && tgt_dim % 4 == 0;
+  for (int l = 0; l < n_layers && ok; ++l)
+    ok = kind[l] == AC_FEAT_TOKENS && H[l] == H[0] && W[l] == W[0] && C[l] % 4 == 0 && (3LL * pre_dim == 8LL * C[l]) && C[l] % 3 == 0;
+  return ok;
+}
+
+extern "C" int ac_patch_aggregate_hl32_supported(const int* kind, const int* C, const int* H, const int* W, int n_layers,
+                                                 int patchsize, int pre_dim, int tgt_dim) {
+  if (!kind || !C || !H || !W) return 0;
+  return agg_is_reg27(kind, C, H, W, n_layers, patchsize, pre_dim, tgt_dim) && tgt_dim % 32 == 0 ? 1 : 0;
+}
+
+static int patch_aggregate_impl(const float* const* feats, const int* kind, const int* C, const int* H, const int* W,
+                                int n_layers, int B, int patchsize, int pre_dim, int tgt_dim, float eps, float* Z,
+                                uint8_t* Zhl, void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, const int* C, const int* H, const int* W,
                                   int n_layers, int B, int patchsize, int pre_dim, int tgt_dim, float eps, float* Z,
                                   void* ws, size_t ws_bytes, void* stream_) {
-  hipStream_t stream = as_stream(stream_);
-  AC_REQUIRE(feats && kind && C && H && W && Z && ws, "ac_patch_aggregate: null pointer");
+  AC_REQUIRE(Z, "ac_patch_aggregate: null pointer");
+  return patch_aggregate_impl(feats, kind, C, H, W, n_layers, B, patchsize, pre_dim, tgt_dim, eps, Z, nullptr, ws, ws_bytes,
+                              as_stream(stream_));
+}
+
+extern "C" int ac_patch_aggregate_hl32(const float* const* feats, const int* kind, const int* C, const int* H, const int* W,
+                                       int n_layers, int B, int patchsize, int pre_dim, int tgt_dim, float eps, void* Z_hl32,
+                                       void* ws, size_t ws_bytes, void* stream_) {
+  AC_REQUIRE(Z_hl32 && ((uintptr_t)Z_hl32 & 15) == 0, "ac_patch_aggregate_hl32: Z_hl32 must be a 16-byte aligned pointer");
+  AC_REQUIRE(ac_patch_aggregate_hl32_supported(kind, C, H, W, n_layers, patchsize, pre_dim, tgt_dim),
+             "ac_patch_aggregate_hl32: only the token-map shape of the register path (K = 3, 3 * pre_dim == 8 * C, identity final "
+             "pool, tgt_dim %% 32 == 0) writes hl32 directly - ask ac_patch_aggregate_hl32_supported first");
+  return patch_aggregate_impl(feats, kind, C, H, W, n_layers, B, patchsize, pre_dim, tgt_dim, eps, nullptr,
+                              static_cast<uint8_t*>(Z_hl32), ws, ws_bytes, as_stream(stream_));
+}
+
+static int patch_aggregate_impl(const float* const* feats, const int* kind, const int* C, const int* H, const int* W,
+                                int n_layers, int B, int patchsize, int pre_dim, int tgt_dim, float eps, float* Z,
+                                uint8_t* Zhl, void* ws, size_t ws_bytes, hipStream_t stream) {
+  AC_REQUIRE(feats && kind && C && H && W && (Z || Zhl) && ws, "ac_patch_aggregate: null pointer");
   AC_REQUIRE(n_layers >= 1 && n_layers <= 4, "ac_patch_aggregate: n_layers=%d must be 1..4", n_layers);
   AC_REQUIRE(patchsize >= 1 && (patchsize & 1), "ac_patch_aggregate: patchsize=%d must be odd (stride-1 unfold keeps the grid)",
              patchsize);
@@ -399,7 +454,7 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
     return ac_fail(AC_EWORKSPACE, "ac_patch_aggregate: workspace too small");
   AggParams prm;
   prm.n_layers = n_layers; prm.k = patchsize; prm.pre = pre_dim; prm.tgt = tgt_dim;
-  prm.H0 = H[0]; prm.W0 = W[0]; prm.eps = eps; prm.Z = Z;
+  prm.H0 = H[0]; prm.W0 = W[0]; prm.eps = eps; prm.Z = Z; prm.Zhl = Zhl;
   float* norm = static_cast<float*>(ws);
   double* partial = reinterpret_cast<double*>(static_cast<uint8_t*>(ws) + align_up((size_t)n_layers * B * 2 * sizeof(double), 256));
   int maxL = 0;
@@ -428,19 +483,23 @@ extern "C" int ac_patch_aggregate(const float* const* feats, const int* kind, co
     maxC = maxC > C[l] ? maxC : C[l];
   }
   // register path: the DINO ViT shape (see agg_pool_tokens_27_8_kernel)
-  bool reg27 = fast && patchsize == 3 && n_layers * pre_dim == tgt_dim && pre_dim % 8 == 0 && pre_dim / 8 <= 256 &&
-               tgt_dim % 4 == 0;
-  for (int l = 0; l < n_layers && reg27; ++l) reg27 = (3LL * pre_dim == 8LL * C[l]) && C[l] % 3 == 0;
+  const bool reg27 = agg_is_reg27(kind, C, H, W, n_layers, patchsize, pre_dim, tgt_dim);
   if (reg27) {
 #ifdef AC_AGG_PER_PATCH          // (same-box A/B: round 2's one workgroup per (patch, layer) at every size)
     const bool per_row = false;
 #else
     const bool per_row = (long long)H[0] * B * n_layers >= 8LL * ac_device_cus();   // >= 8 row-workgroups per CU
 #endif
-    if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel, dim3(H[0], B, n_layers), dim3(256), 0, stream, prm);
-    else hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
+    if (Zhl) {
+      if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel<true>, dim3(H[0], B, n_layers), dim3(256), 0, stream, prm);
+      else hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel<true>, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
+    } else {
+      if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel<false>, dim3(H[0], B, n_layers), dim3(256), 0, stream, prm);
+      else hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel<false>, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
+    }
     return ac_check_launch("ac_patch_aggregate(tokens, registers)");
   }
+  if (Zhl) return ac_fail(AC_EINVAL, "ac_patch_aggregate_hl32: shape not on the register path");
   if (fast) {
     const bool identity = (n_layers * pre_dim == tgt_dim);
     size_t flds = ((size_t)patchsize * patchsize * (maxC + 4) + (identity ? 0 : (size_t)n_layers * pre_dim)) * sizeof(float);

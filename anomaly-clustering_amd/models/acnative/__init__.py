@@ -31,7 +31,7 @@ class BlockWeights(_c.Structure):
                                    "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
-ABI_VERSION = 500      # include/ac_hip.h AC_ABI_VERSION
+ABI_VERSION = 600      # include/ac_hip.h AC_ABI_VERSION
 
 # name -> (restype, argtypes): every symbol include/ac_hip.h declares
 SIGNATURES = {
@@ -51,6 +51,9 @@ SIGNATURES = {
     "ac_patch_aggregate_workspace_bytes": (_sz, [_i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _i, _i]),
     "ac_patch_aggregate": (_i, [_c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i),
                                 _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
+    "ac_patch_aggregate_hl32_supported": (_i, [_c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _i, _i, _i, _i]),
+    "ac_patch_aggregate_hl32": (_i, [_c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i),
+                                     _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "ac_unfold_patches": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ac_adaptive_avg_pool_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "ac_pair_min_dist_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
@@ -313,9 +316,8 @@ def maxpool_nhwc(x, k, stride, pad):
 
 
 # --------------------------------------------------------- patch aggregation
-def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5, out=None):
-    """features: list of fp32 device tensors, each [B, T, C] (token map with CLS) or [B, C, H, W].
-    Returns Z fp32 [B * H0 * W0, tgt_dim] (written into `out` when given) and the per-layer patch grids."""
+def _aggregate_layout(features):
+    """The feature maps as the library takes them: (tensors kept alive, ptrs, kinds, Cs, Hs, Ws, n, B)."""
     n = len(features)
     feats, nhwc = [], []
     for f in features:
@@ -340,6 +342,13 @@ def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5, out=None):
             raise ValueError("feature map must be [B,T,C] or [B,C,H,W]")
         if f.shape[0] != B:
             raise ValueError("feature maps disagree on batch size")
+    return feats, ptrs, kinds, Cs, Hs, Ws, n, B
+
+
+def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5, out=None):
+    """features: list of fp32 device tensors, each [B, T, C] (token map with CLS) or [B, C, H, W].
+    Returns Z fp32 [B * H0 * W0, tgt_dim] (written into `out` when given) and the per-layer patch grids."""
+    feats, ptrs, kinds, Cs, Hs, Ws, n, B = _aggregate_layout(features)
     nbytes = lib().ac_patch_aggregate_workspace_bytes(n, Cs, Hs, Ws, B, patchsize, pre_dim, tgt_dim)
     ws = workspace(nbytes, feats[0].device)
     if out is None:
@@ -352,6 +361,30 @@ def patch_aggregate(features, patchsize, pre_dim, tgt_dim, eps=1e-5, out=None):
     _check(lib().ac_patch_aggregate(ptrs, kinds, Cs, Hs, Ws, n, B, patchsize, pre_dim, tgt_dim, float(eps),
                                     Z.data_ptr(), ws.data_ptr(), nbytes, _stream()))
     return Z, [[Hs[j], Ws[j]] for j in range(n)]
+
+
+def patch_aggregate_hl32_supported(features, patchsize, pre_dim, tgt_dim):
+    """Can ac_patch_aggregate_hl32 take these maps (the token-map shape of the register path: DINO ViT-B/8)?"""
+    if any(f.dim() != 3 or f.dtype != torch.float32 for f in features):
+        return False
+    _, _, kinds, Cs, Hs, Ws, n, _ = _aggregate_layout(features)
+    return bool(lib().ac_patch_aggregate_hl32_supported(kinds, Cs, Hs, Ws, n, patchsize, pre_dim, tgt_dim))
+
+
+def patch_aggregate_hl32(features, patchsize, pre_dim, tgt_dim, out_hl, eps=1e-5):
+    """The aggregation with its rows written straight into the hl32 rows `out_hl` (uint8 [B * H0 * W0, tgt_dim * 4], e.g.
+    Packed.hl of a block of B images): byte for byte pack_images(patch_aggregate(...)).hl, without the fp32 Z in between.
+    The squared norms are NOT produced (a received shard's norms travel with its taps)."""
+    feats, ptrs, kinds, Cs, Hs, Ws, n, B = _aggregate_layout(features)
+    rows = B * Hs[0] * Ws[0]
+    _dev(out_hl, torch.uint8, "out_hl")
+    if out_hl.numel() != rows * tgt_dim * 4 or out_hl.device != feats[0].device:
+        raise ValueError("out_hl has %d bytes, the batch needs %d" % (out_hl.numel(), rows * tgt_dim * 4))
+    nbytes = lib().ac_patch_aggregate_workspace_bytes(n, Cs, Hs, Ws, B, patchsize, pre_dim, tgt_dim)
+    ws = workspace(nbytes, feats[0].device)
+    _check(lib().ac_patch_aggregate_hl32(ptrs, kinds, Cs, Hs, Ws, n, B, patchsize, pre_dim, tgt_dim, float(eps),
+                                         out_hl.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    return out_hl
 
 
 def unfold_patches(x, patchsize, stride=1):

@@ -162,6 +162,19 @@ class AnomalyClusteringCore(torch.nn.Module):
         return Zr.reshape(n, Zr.shape[0] // n, Zr.shape[-1])
 
     @torch.no_grad()
+    def aggregate_taps_hl32(self, feats, out_hl):
+        """aggregate_taps with the rows written straight into the hl32 rows `out_hl` (Packed.hl of the block): the bytes
+        pack_images(aggregate_taps(feats)).hl would hold, without the fp32 Z (12.85 MB per image written and read back) in
+        between.  For blocks that are only multiplied - the shards received over the ring.  False when the shape is not the
+        one the fused kernel serves (the caller then aggregates and packs)."""
+        args = (list(feats), self.patch_maker.patchsize, self.forward_modules["preprocessing"].output_dim,
+                self.forward_modules["preadapt_aggregator"].target_dim)
+        if not acnative.patch_aggregate_hl32_supported(*args):
+            return False
+        acnative.patch_aggregate_hl32(*args, out_hl)
+        return True
+
+    @torch.no_grad()
     def embed_taps_device(self, images, batch_size=32):
         """Only the tapped feature maps of the images ([N, ...] per extracted layer, device-resident), no aggregation:
         what a category too large to hold Z (12.85 MB per image) next to its packed copy keeps instead - 4.8 MB per

@@ -216,22 +216,31 @@ class Taps:
     """The tapped feature maps of a block of images ([n, 785, 768] x 2 for ViT-B/8: 4.8 MB per image) - what goes round
     the ring instead of the packed embeddings (12.85 MB per image): the receiver runs the aggregation kernel on them
     (17.7 MB of HBM traffic per image, microseconds) and packs the result, bit-identical to what the sender holds.
-    Same surface as a packed block as far as the ring is concerned: n, slice(), tensors()."""
+    Same surface as a packed block as far as the ring is concerned: n, slice(), tensors().
+    sq (round 6): the squared norms [n, P] of the images' packed rows, when the sender has them (with_norms: 3 KB per
+    image next to 4.8 MB) - the receiver then writes the hl32 rows straight from the aggregation kernel and never forms
+    the fp32 Z of a block it only multiplies (HipOps.taps_to_packed)."""
 
-    def __init__(self, feats, n):
-        self.feats, self.n = list(feats), int(n)
+    def __init__(self, feats, n, sq=None):
+        self.feats, self.n, self.sq = list(feats), int(n), sq
+
+    def with_norms(self, sq_rows, P):
+        """These taps + the squared norms of their packed rows (fp32 [n * P], Packed.sq of the same images).  An empty
+        shard gets an empty [0, P]: every rank's taps must have the same tensors (the ring's receive buffers mirror them)."""
+        return Taps(self.feats, self.n, sq_rows.reshape(self.n, P))
 
     def slice(self, lo, hi):
-        return Taps([f[lo:hi] for f in self.feats], hi - lo)
+        return Taps([f[lo:hi] for f in self.feats], hi - lo, None if self.sq is None else self.sq[lo:hi])
 
     def tensors(self):
-        return self.feats
+        return self.feats if self.sq is None else self.feats + [self.sq]
 
     def bytes_per_image(self):
-        return sum(int(np.prod(f.shape[1:])) * f.element_size() for f in self.feats)
+        return sum(int(np.prod(f.shape[1:])) * f.element_size() for f in self.tensors())
 
     def empty_like(self, n):
-        return Taps([torch.empty((n,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in self.feats], n)
+        return Taps([torch.empty((n,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in self.feats], n,
+                    None if self.sq is None else torch.empty((n,) + tuple(self.sq.shape[1:]), dtype=self.sq.dtype, device=self.sq.device))
 
     @property
     def device(self):
@@ -309,10 +318,25 @@ class HipOps:
         return Zs
 
     def taps_to_packed(self, taps):
-        """A received block of taps -> its packed embeddings (aggregate + pack: the sender's own Z, bit for bit)."""
+        """A received block of taps -> its packed embeddings (aggregate + pack: the sender's own Z, bit for bit).  When the
+        sender's norms came along (Taps.sq) and the shape is the fused kernel's, the aggregation writes the hl32 rows itself
+        and the norms are the sender's: the same bytes without the fp32 Z of the block (25.7 MB of HBM traffic per image)."""
         if taps.n == 0:
             return self.pack(self._empty(False))
+        if taps.sq is not None and os.environ.get("AC_RING_FUSED_DECODE", "1") != "0":
+            P, D = self.zshape()
+            hl = torch.empty((taps.n * P, D * 4), dtype=torch.uint8, device=taps.device)
+            if self.core.aggregate_taps_hl32(taps.feats, hl):
+                return self.acnative.Packed(hl, taps.sq.reshape(-1), taps.n, P, D)
         return self.pack(self.core.aggregate_taps(taps.feats))
+
+    def taps_with_norms(self, taps, packed):
+        """What a ring of taps sends: the taps + the norms of the same images' packed rows (see Taps.sq)."""
+        if taps.sq is not None:
+            return taps
+        if taps.n != packed.n:
+            raise ValueError("taps of %d images, packed rows of %d" % (taps.n, packed.n))
+        return taps.with_norms(packed.sq, packed.P)
 
     # ---- a category too large for Z next to its packed copy keeps the taps instead of Z (run_category's `lean`)
     LEAN_CHUNK = 128          # images aggregated at a time when Z is rebuilt from taps (1.6 GB of Z)
@@ -690,9 +714,12 @@ class _UnsupJob:
             self.by_step.setdefault(item[1], []).append(item)
 
     def post(self):
-        self.ring = _Ring(self.ops, self.send if self.send is not None else self.pk, self.counts, self.rank, self.world,
+        send = self.send
+        if send is not None and hasattr(self.ops, "taps_with_norms"):
+            send = self.ops.taps_with_norms(send, self.pk)        # the packed rows' norms travel with the taps
+        self.ring = _Ring(self.ops, send if send is not None else self.pk, self.counts, self.rank, self.world,
                           self.group, last_step=self.last_step, remote_bytes=self.remote_bytes,
-                          decode=self.ops.taps_to_packed if self.send is not None else None, rot=self.rot)
+                          decode=self.ops.taps_to_packed if send is not None else None, rot=self.rot)
 
     def run(self, step):
         ops, P, acc, shift, lo = self.ops, self.P, self.acc, self.shift, self.lo
@@ -822,9 +849,12 @@ class _SupJob:
         self.q16 = ops.h16(self.pk)
 
     def _new_ring(self):
-        return _Ring(self.ops, self.send if self.send is not None else self.bank, self.counts, self.rank, self.world,
+        send = self.send
+        if send is not None and hasattr(self.ops, "taps_with_norms"):
+            send = self.ops.taps_with_norms(send, self.bank)       # the packed rows' norms travel with the taps
+        return _Ring(self.ops, send if send is not None else self.bank, self.counts, self.rank, self.world,
                      self.group, last_step=self.last_step, remote_bytes=self.remote_bytes,
-                     decode=self.ops.taps_to_packed if self.send is not None else None, rot=self.rot)
+                     decode=self.ops.taps_to_packed if send is not None else None, rot=self.rot)
 
     def post(self):
         self.ring = self._new_ring()
@@ -1211,12 +1241,15 @@ def run_categories(ops, items, supervised="unsupervised", tau=1.0, k=1, train_ra
         # run_category, which has the lean path; the one-job order below holds full Z.  Every rank must take the same
         # branch (the two orders post different collectives), so the ranks agree on the flag first.  (Round-4 advice: the
         # one-job path used to read Z_locs[c].shape of a Taps object and to embed large groups with full Z.)
-        lean_grp = Z_locs is not None and any(isinstance(Z_locs[c], Taps) for c in grp)      # (the same on every rank)
+        has_taps = Z_locs is not None and any(isinstance(Z_locs[c], Taps) for c in grp)      # may differ from rank to rank
         grp_images = sum(per_rank[c] for c in grp)                                           # test + bank images of the largest shards
+        small = bool(getattr(ops, "never_lean", lambda _n: False)(grp_images))               # shapes only: the same on every rank
         if lean is not None:
-            lean_grp = lean_grp or bool(lean)
-        elif not lean_grp and not getattr(ops, "never_lean", lambda _n: False)(grp_images):
-            lean_grp = bool(getattr(ops, "wants_lean", lambda _n: False)(grp_images))
+            lean_grp = has_taps or bool(lean)          # the caller's word (and its Z_locs) must be the same on every rank
+        elif small and Z_locs is None:
+            lean_grp = False                           # nobody can want it, nobody can hold Taps: nothing to agree on
+        else:
+            lean_grp = has_taps or (not small and bool(getattr(ops, "wants_lean", lambda _n: False)(grp_images)))
             if world > 1:
                 flag = torch.tensor([int(lean_grp)], dtype=torch.int32, device=_flag_device(ops, items[grp[0]]["images"]))
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)

@@ -49,8 +49,9 @@ extern "C" {
 
 /* ABI revision: changes whenever an entry point changes meaning or a new one is added; a binding checks it at load
  * time (models/acnative does: a stale library under a newer binding - or the reverse - fails there, not in a kernel).
- * 500 = round 5: ac_alpha_softmax is the 7-argument form again, the fp32 copy moved to ac_alpha_softmax_f32. */
-#define AC_ABI_VERSION 500
+ * 500 = round 5: ac_alpha_softmax is the 7-argument form again, the fp32 copy moved to ac_alpha_softmax_f32.
+ * 600 = round 6: ac_patch_aggregate_hl32 / ac_patch_aggregate_hl32_supported added. */
+#define AC_ABI_VERSION 600
 int ac_version(void);
 const char* ac_last_error(void);
 
@@ -157,6 +158,17 @@ size_t ac_patch_aggregate_workspace_bytes(int n_layers, const int* C, const int*
 int ac_patch_aggregate(const float* const* feats, const int* kind, const int* C, const int* H,
                        const int* W, int n_layers, int B, int patchsize, int pre_dim, int tgt_dim,
                        float eps, float* Z, void* ws, size_t ws_bytes, void* stream);
+
+/* The same chain with the rows written as hl32 [B * H0*W0, tgt_dim * 4 bytes] - the operand format of the distance
+ * kernels (ac_pack_hl32 of the fp32 Z above, byte for byte) - for blocks that are only ever multiplied: the shards a rank
+ * receives over the ring (their squared norms travel with them).  Only the token-map shape of the register path (K = 3,
+ * 3 * pre_dim == 8 * C per layer, identity final pool, tgt_dim % 32 == 0: the DINO ViT-B/8 configuration);
+ * ac_patch_aggregate_hl32_supported says whether a shape qualifies (1 / 0), the operator refuses the others. */
+int ac_patch_aggregate_hl32_supported(const int* kind, const int* C, const int* H, const int* W, int n_layers,
+                                      int patchsize, int pre_dim, int tgt_dim);
+int ac_patch_aggregate_hl32(const float* const* feats, const int* kind, const int* C, const int* H,
+                            const int* W, int n_layers, int B, int patchsize, int pre_dim, int tgt_dim,
+                            float eps, void* Z_hl32, void* ws, size_t ws_bytes, void* stream);
 
 /* The pieces of the chain above as separate operators, for callers that use the reference's
  * modules one by one (PatchMaker.patchify, MeanMapper.forward, Aggregator.forward): */

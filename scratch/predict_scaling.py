@@ -90,7 +90,7 @@ def main():
     for c in cats:
         Zc, tc = ops.embed(images[c], want_taps=True)
         pk_all[c] = ops.pack(Zc)
-        src_all[c] = tc if taps_mode else pk_all[c]
+        src_all[c] = ops.taps_with_norms(tc, pk_all[c]) if taps_mode else pk_all[c]     # (what a real ring carries: taps + norms)
         del Zc
     per_image_bytes = src_all[cats[0]].bytes_per_image() if taps_mode else P * (D * 4 + 4)
 

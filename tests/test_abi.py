@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), "libac_hip.so does not export %s" % name
     assert sorted(acnative.SIGNATURES) == names, "binding table and header disagree"
-    assert lib.ac_version() == acnative.ABI_VERSION == 500      # include/ac_hip.h AC_ABI_VERSION
+    assert lib.ac_version() == acnative.ABI_VERSION == 600      # include/ac_hip.h AC_ABI_VERSION
 
 
 def test_header_cites_reference_for_every_compute_entry_point():

@@ -127,3 +127,28 @@ def test_row_kernel_equals_the_per_patch_kernel_bitwise(dev):
     for rows in (slice(0, 28), slice(13 * 28, 14 * 28), slice(27 * 28, 28 * 28)):
         ok, mx = _close(mine[rows], ref[rows])
         assert ok, mx
+
+
+def test_hl32_rows_straight_from_the_aggregation_equal_pack_of_Z_bitwise(dev):
+    """Round 6: ac_patch_aggregate_hl32 writes the operand rows of the distance kernels itself (the shards a rank receives over
+    the ring: their fp32 Z need not exist).  Byte for byte ac_pack_hl32 of ac_patch_aggregate's Z - through the row kernel (80
+    images) and through the per-patch kernel (20 images) - and refused, with the support query saying so, for every shape
+    off the register path (a CNN map, pre_dim 1024, patch size 5)."""
+    import acnative
+    fa = torch.from_numpy(gaussish_tensor((80, 785, 768), salt=31, scale=1.4)) + 0.2
+    fb = torch.from_numpy(gaussish_tensor((80, 785, 768), salt=32, scale=0.9)) - 0.1
+    fa, fb = fa.to(dev), fb.to(dev)
+    for n in (80, 20):
+        feats = [fa[:n].contiguous(), fb[:n].contiguous()]
+        assert acnative.patch_aggregate_hl32_supported(feats, 3, 2048, 4096)
+        Z, _ = acnative.patch_aggregate(feats, 3, 2048, 4096)
+        ref = acnative.pack_images(Z.reshape(n, 784, 4096))
+        hl = torch.full((n * 784, 4096 * 4), 0xAB, dtype=torch.uint8, device=dev)
+        acnative.patch_aggregate_hl32(feats, 3, 2048, 4096, hl)
+        assert torch.equal(hl, ref.hl), n
+    cnn = [torch.zeros((2, 512, 28, 28), device=dev), torch.zeros((2, 1024, 14, 14), device=dev)]
+    assert not acnative.patch_aggregate_hl32_supported(cnn, 3, 1024, 1024)
+    assert not acnative.patch_aggregate_hl32_supported([fa[:2].contiguous()], 3, 1024, 1024)
+    assert not acnative.patch_aggregate_hl32_supported([fa[:2].contiguous(), fb[:2].contiguous()], 5, 2048, 4096)
+    with pytest.raises(RuntimeError, match="register path"):
+        acnative.patch_aggregate_hl32([fa[:2].contiguous()], 3, 1024, 1024, torch.empty((2 * 784, 1024 * 4), dtype=torch.uint8, device=dev))
