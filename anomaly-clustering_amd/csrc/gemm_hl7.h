@@ -91,16 +91,6 @@ constexpr int RECT_WINDOW_TILES_PER_CU = 160;
 #ifndef AC_G7_PIN_AGPR
 #define AC_G7_PIN_AGPR 0
 #endif
-// Pace of a stage's 14 transfers (A/B builds, round 6: as buffer loads they leave in a burst 2-3x tighter than the flat form's, and
-// the L2 hit rate of the launch falls from 75 to 72 %): AC_G7_DMA_PACE = s_sleep argument behind every transfer (0: none);
-// AC_G7_SPLIT_B = c > 0: the column operand's six transfers leave at column step c of the NEXT stage instead of together with the
-// row operand's eight (B(t+2) at step c of stage t into the slot B(t-1) left; the prologue then issues B(0), B(1) only).
-#ifndef AC_G7_DMA_PACE
-#define AC_G7_DMA_PACE 0
-#endif
-#ifndef AC_G7_SPLIT_B
-#define AC_G7_SPLIT_B 0
-#endif
 #ifndef AC_G7_KATTR
 #define AC_G7_KATTR
 #endif
@@ -274,7 +264,6 @@ __global__ __launch_bounds__(threads_of(MT), MT == 4 ? 2 : 1) AC_G7_KATTR void k
       uint8_t* const d = (AC_ABLATE7 & 32) ? smem + LDS_BYTES + LDS_EXTRA + (wave & (LW - 1)) * 1024
                                            : dst + (j * LW + (wave & (LW - 1))) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)d, 16, dma_voff, (int)(8u * LW * j * ld32) + t * 128, 0, 0);
-      if (AC_G7_DMA_PACE) __builtin_amdgcn_s_sleep(AC_G7_DMA_PACE);
     }
   };
   auto dmaA = [&](int t, int slot) { if (loader) dma(tbA, t, Aring + slot * A_HALF, BM / (8 * LW)); };
@@ -338,7 +327,7 @@ __global__ __launch_bounds__(threads_of(MT), MT == 4 ? 2 : 1) AC_G7_KATTR void k
     dmaA(0, 0);
     dmaB(0, 0);
     if (nk > 1) { dmaA(1, 1); dmaB(1, 1); }
-    if (nk > 2 && !AC_G7_SPLIT_B) dmaB(2, 2);
+    if (nk > 2) dmaB(2, 2);
   };
   tile_of(id, total, tiles_m, tiles_n, group_m, epi, tm, tn, tcache);            // block-uniform
   m0 = tm * BM;
@@ -361,7 +350,7 @@ __global__ __launch_bounds__(threads_of(MT), MT == 4 ? 2 : 1) AC_G7_KATTR void k
 
     // the first two of the five prologue transfers must have landed (only the waves that issued them wait)
     if (loader) {
-      if (nk > 2 && !AC_G7_SPLIT_B) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * LW) + 2 * (BN / (8 * LW))) : "memory");      // A(1) B(1) B(2) may fly
+      if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * LW) + 2 * (BN / (8 * LW))) : "memory");      // A(1) B(1) B(2) may fly
       else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * LW) + BN / (8 * LW)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -419,13 +408,9 @@ __global__ __launch_bounds__(threads_of(MT), MT == 4 ? 2 : 1) AC_G7_KATTR void k
           frag(Bn, b_hi, 0, nh, bl);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (AC_G7_SPLIT_B && ni == AC_G7_SPLIT_B && more2) {
-          dmaB(kt + 2, sb == 0 ? B_SLOTS - 1 : sb - 1);           // B(kt-1)'s slot: free since the end of the stage before
-          __builtin_amdgcn_sched_barrier(0);
-        }
         if (last && more1) {
           if (more2 && !(AC_ABLATE7 & 1)) dmaA(kt + 2, kt & 1);   // A(kt) went to registers a stage ago
-          if (more3 && !(AC_ABLATE7 & 1) && !AC_G7_SPLIT_B) dmaB(kt + 3, sb);       // nobody reads B(kt) any more
+          if (more3 && !(AC_ABLATE7 & 1)) dmaB(kt + 3, sb);       // nobody reads B(kt) any more
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
