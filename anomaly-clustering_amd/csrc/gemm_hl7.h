@@ -17,7 +17,7 @@
 // tiles x 3 passes = 12 MFMAs each); the next B fragment is read during the current step, and in the LAST step of a
 // stage every A fragment is re-read for the next stage right after its final MFMA.  LDS 136 KB: A (256 rows, 32 KB per
 // stage) in a 2-slot ring - it goes to registers a stage ahead - and B (192 rows, 24 KB) in a 3-slot ring, filled by
-// global_load_lds from waves 0-3.  ONE barrier per stage t, X(t), before the last column step: everybody's share of
+// LDS-DMA from waves 0-3 (round 6: buffer loads with scalar burst / stage offsets, see the DMA map in the kernel).  ONE barrier per stage t, X(t), before the last column step: everybody's share of
 // A(t+1), B(t+1) has landed; nobody reads B(t) any more and A(t) went to registers a stage ago
 //   -> A(t+2) goes into A(t)'s slot (one stage of cover), B(t+3) into B(t)'s slot (two stages).
 // Tiles: persistent workgroups pull them from gemm_hl2.h's per-XCD-slot queues (dynamic), or one workgroup per tile.
@@ -43,6 +43,10 @@
 // (scratch/exp_g7_stagger_and_knobs.patch, scratch/exp_g7_early_prologue.patch): a half-stage stagger of waves 4-7
 // (+10 ... +18 %), DMA issue from all eight waves (+8 %), priority variants (0 ... +1 %), the next tile's first stages
 // issued before the epilogue (equal time, +19 % fabric traffic).
+// Round 6 (profiles/r06_allpairs_buffer_dma_ab.txt): the transfers as buffer loads, 83 -> 16 non-MFMA VALU per stage in the
+// loader waves, -0.9 ... -1.2 % same-box; what the DMA path costs, taken apart by the AC_ABLATE7 bits 8 / 16 / 32: instructions
+// 0.7 ms, L2 -> LDS bandwidth 0.8, L2 misses 3.2, fresh operands under the MFMAs 1.6.  MT = 8 (four waves, 512 registers):
+// hipcc spills an accumulator set in the k loop (profiles/r06_allpairs_512reg_resource_report.txt) - compile-only.
 #pragma once
 #include "gemm_hl2.h"
 
