@@ -323,10 +323,18 @@ __global__ __launch_bounds__(256) void agg_pool_tokens_27_8_kernel(AggParams prm
 // bit-identical.  Columns are kept in four named register sets rotated by a 4-step unrolled loop (no copies); the loads
 // of column x + 2 fly while patch x is summed.  Small batches (a rank's 11 images) keep one workgroup per patch: a row
 // per workgroup would leave the chip a third full.
+// Round 6: the workgroups of ONE (image, layer) - its H0 patch rows, each of which reads the token rows y - 1, y, y + 1 - run on ONE XCD
+// (workgroups go to the XCDs round robin by their linear id: id & 7 = XCD, id >> 3 = its slot there; XCD x works the units x, x + 8, ...
+// row by row), so a token row is fetched over the fabric once and met in that XCD's L2 by its two neighbours.  The plain (y, b, l) grid
+// dealt the rows of an image to all eight XCDs: every token row crossed the fabric three times (1171 MB fetched for 400 MB of taps at 83
+// images, profiles/r05_bench_pmc.json).  Same arithmetic per workgroup: bit-identical.
 template <bool HL>
-__global__ __launch_bounds__(256) void agg_pool_tokens_27_8_row_kernel(AggParams prm) {
+__global__ __launch_bounds__(256) void agg_pool_tokens_27_8_row_kernel(AggParams prm, int B) {
   const int t = threadIdx.x;
-  const int y = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int unit = (slot / prm.H0) * 8 + xcd, y = slot - (slot / prm.H0) * prm.H0;       // unit = image + B * layer
+  if (unit >= B * prm.n_layers) return;                                                  // (the grid is padded to whole rounds of 8 units)
+  const int b = unit % B, l = unit / B;
   if (t * 8 >= prm.pre) return;
   const AggLayer L = prm.layer[l];
   const int HW = L.H * L.W;
@@ -490,11 +498,12 @@ static int patch_aggregate_impl(const float* const* feats, const int* kind, cons
 #else
     const bool per_row = (long long)H[0] * B * n_layers >= 8LL * ac_device_cus();   // >= 8 row-workgroups per CU
 #endif
+    const unsigned row_grid = 8u * (unsigned)H[0] * (unsigned)((B * n_layers + 7) / 8);      // 8 XCDs x H0 rows x units per XCD
     if (Zhl) {
-      if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel<true>, dim3(H[0], B, n_layers), dim3(256), 0, stream, prm);
+      if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel<true>, dim3(row_grid), dim3(256), 0, stream, prm, B);
       else hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel<true>, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
     } else {
-      if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel<false>, dim3(H[0], B, n_layers), dim3(256), 0, stream, prm);
+      if (per_row) hipLaunchKernelGGL(agg_pool_tokens_27_8_row_kernel<false>, dim3(row_grid), dim3(256), 0, stream, prm, B);
       else hipLaunchKernelGGL(agg_pool_tokens_27_8_kernel<false>, dim3(H[0] * W[0], B, n_layers), dim3(256), 0, stream, prm);
     }
     return ac_check_launch("ac_patch_aggregate(tokens, registers)");
