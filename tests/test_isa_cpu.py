@@ -69,6 +69,18 @@ def test_all_pairs_kernels_keep_their_k_loops_in_registers_and_their_ticket_in_f
             assert not any(t.startswith("scratch_") for t in b), "%s: spill inside the k loop" % name
         tickets = [i for i, t in enumerate(lines) if t.startswith("global_atomic_add") and "sc0" in t]
         assert len(tickets) >= 2, "%s: the ticket atomic was rewritten" % name      # first tile + tile loop (+ steals)
+    # round 6: the 256x192 kernel's transfers are buffer loads with SCALAR burst / stage offsets - no 64-bit address arithmetic and no
+    # waterfall loop (a descriptor hipcc cannot prove uniform: v_readfirstlane x 4 + s_and_saveexec round every transfer) in the k loop,
+    # at most 24 vector instructions beside the MFMAs and the accumulator flush in a stage block (round 5: 83)
+    hot7 = [b for b in _blocks(g7[0]) if sum(t.startswith("v_mfma") for t in b) >= 36]
+    assert sum(sum(bool(re.match(r"buffer_load_dwordx4 .* lds$", t)) for t in b) for b in _blocks(g7[0])) >= 14 * 2, "gemm7: the DMA is not buffer_load ... lds"
+    dma_blocks = [b for b in hot7 if sum(" lds" in t and t.startswith("buffer_load") for t in b) >= 14]     # (a tile's prologue issues 36 too: not the k loop)
+    assert dma_blocks, "gemm7: no k-loop block issues a whole stage's transfers"
+    for b in hot7:
+        assert not any(t.startswith(("v_mad_u64_u32", "v_lshl_add_u64", "s_and_saveexec")) for t in b), "gemm7: per-transfer address arithmetic / waterfall in the k loop"
+    for b in dma_blocks:
+        valu = [t for t in b if t.startswith("v_") and not t.startswith(("v_mfma", "v_pk_add_f32"))]
+        assert len(valu) <= 24, "gemm7: %d vector instructions in the DMA block of a stage" % len(valu)
     # the tile loop's ticket of the 256x192 kernel travels under the last stages: nothing waits for it on the spot
     lines = g7[0]
     in_loop = [i for i, t in enumerate(lines) if t.startswith("global_atomic_add") and "sc0" in t]
