@@ -306,6 +306,9 @@ def test_config5b_full_size_schedule_with_the_launches_as_bookkeeping(dev, core)
     torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info(dev)
     assert ops.wants_lean(n) and not ops.wants_lean(83)
+    # ... and the shortcut by which a multi-rank job skips the agreement on it altogether: a function of the shapes and the device
+    # model only (216 images: a rank's share of all 15 categories on 8 GPUs; 1 400 images are an eighth of the HBM)
+    assert ops.never_lean(216) and ops.never_lean(1300) and not ops.never_lean(1725) and not ops.never_lean(n)
     tap_bytes = sum(int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() for shape, dt in ops._tapshapes)
     assert tap_bytes == 2 * 785 * 768 * 4
     lean_bytes = n * tap_bytes + n * P * (D * 4 + 4) + 2 * MINBUF_BYTES + n * P * 8
